@@ -1,0 +1,102 @@
+/* mmt_hip.h — C ABI of libmmt_hip.so, the MI355X (gfx950) implementation of the attention hot path
+ * of frankaging/Multimodal-Transformer.
+ *
+ * The reference has no FFI: its boundary for this path is the Python class surface of
+ * transformer/{SFT,MFT,B2-Trans}/multiTransformer.py.  Each entry point below replaces
+ * the forward (or the autograd backward) of one of those classes and is what a binding for the
+ * reference would call (ctypes stub: INTEGRATION.md).  Conventions:
+ *   - every pointer is a DEVICE pointer unless named host_*; tensors are contiguous fp32 in the
+ *     reference's own layouts: activations (B,T,d) row-major, mask (B,T,1) float {0,1} (a window is
+ *     blanked where mask == 0, multiTransformer.py:30), nn.Linear weights (out,in);
+ *   - the library allocates nothing: the caller passes a workspace of *_workspace_bytes() bytes that
+ *     MUST be zero-filled when first created and may then be reused for calls of the same shape
+ *     (pad regions are never written; saved-for-backward tensors live in it between a forward and its
+ *     backward);
+ *   - all work is enqueued on `stream` (a hipStream_t); nothing synchronises, so calls are capturable
+ *     into a hipGraph;
+ *   - return 0 on success, non-zero MMT_E* on error with a message in mmt_last_error() (thread local).
+ *     Asynchronous HIP faults surface at the caller's next synchronisation, as in PyTorch.
+ */
+#ifndef MMT_HIP_H
+#define MMT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMT_OK 0
+#define MMT_EINVAL 1      /* bad shape / null pointer */
+#define MMT_EUNSUPPORTED 2 /* e.g. d_k > 32, d % 4 != 0 */
+#define MMT_EWORKSPACE 3  /* workspace too small */
+#define MMT_EHIP 4        /* a HIP runtime call failed */
+
+typedef void* mmt_stream_t; /* hipStream_t */
+
+int mmt_abi_version(void);
+const char* mmt_last_error(void);
+
+/* ---- Encoder stack: N x (pre-norm self-attention sublayer + pre-norm FFN sublayer) + final LayerNorm.
+ * Replaces Encoder.forward(x, mask)                       transformer/MFT/multiTransformer.py:73-76
+ *   with EncoderLayer.forward / SublayerConnection.forward                              :103-104,114-116
+ *        MultiHeadedAttention.forward + attention()                                      :22-34,47-65
+ *        PositionwiseFeedForward.forward                                                 :19-20
+ *        LayerNorm.forward (unbiased std, eps added to std)                              :88-91
+ * `params`: one flat fp32 buffer, per layer in the reference's registration order
+ *   self_attn.linears.{0,1,2,3}.{weight(d,d),bias(d)}, feed_forward.w_1.{weight(f,d),bias(f)},
+ *   feed_forward.w_2.{weight(d,f),bias(d)}, sublayer.0.norm.{a_2,b_2}, sublayer.1.norm.{a_2,b_2},
+ * followed by the stack's norm.{a_2,b_2}.  mmt_encoder_param_count() gives its length.
+ * Eval-mode (dropout = identity) when dropout_p == 0; see mmt_encoder_forward's `dropout_p`, `seed`. */
+size_t mmt_encoder_param_count(int d, int f, int n_layers);
+size_t mmt_encoder_workspace_bytes(int B, int T, int d, int h, int f, int n_layers);
+
+int mmt_encoder_forward(const float* x, const float* mask, const float* params, float* y,
+                        void* workspace, size_t workspace_bytes,
+                        int B, int T, int d, int h, int f, int n_layers, float eps,
+                        float dropout_p, uint64_t seed, mmt_stream_t stream);
+
+/* Backward of the above (what torch autograd derives for the reference).  Must follow a forward on the
+ * same workspace.  dx: (B,T,d); dparams: flat, same layout as params (fully overwritten). */
+int mmt_encoder_backward(const float* dy, const float* x, const float* mask, const float* params,
+                         float* dx, float* dparams,
+                         void* workspace, size_t workspace_bytes,
+                         int B, int T, int d, int h, int f, int n_layers, float eps,
+                         float dropout_p, uint64_t seed, mmt_stream_t stream);
+
+/* ---- LayerNorm alone.  Replaces LayerNorm.forward            transformer/MFT/multiTransformer.py:88-91
+ * stats: (M,2) fp32 scratch kept for the backward (mean, 1/(std+eps)).
+ * colpart: scratch of mmt_layernorm_scratch_floats(M,d) floats. */
+size_t mmt_layernorm_scratch_floats(int M, int d);
+int mmt_layernorm_forward(const float* x, const float* a_2, const float* b_2, float* y, float* stats,
+                          int M, int d, float eps, mmt_stream_t stream);
+int mmt_layernorm_backward(const float* dy, const float* x, const float* a_2, const float* stats,
+                           float* dx, float* da_2, float* db_2, float* scratch,
+                           int M, int d, float eps, mmt_stream_t stream);
+
+/* ---- Scaled dot-product attention core on already-projected q, k, v.
+ * Replaces attention(query, key, value, mask)                 transformer/MFT/multiTransformer.py:22-34
+ * q,k,v,ctx: (B,T,d) fp32 with head `i` in columns [i*d/h,(i+1)*d/h) (the layout before the reference's
+ * .view(B,-1,h,d_k).transpose(1,2)); mask (B,T,1) blanks QUERY rows; may be NULL. */
+size_t mmt_sdpa_workspace_bytes(int B, int T, int d, int h);
+int mmt_sdpa_forward(const float* q, const float* k, const float* v, const float* mask, float* ctx,
+                     void* workspace, size_t workspace_bytes, int B, int T, int d, int h, mmt_stream_t stream);
+int mmt_sdpa_backward(const float* dctx, const float* mask, float* dq, float* dk, float* dv,
+                      void* workspace, size_t workspace_bytes, int B, int T, int d, int h, mmt_stream_t stream);
+
+/* ---- Fused affine map  y = act(x W^T + b) [* rowscale] on bf16 MFMA.
+ * Replaces nn.Linear (+ F.relu) call sites of the path: PositionwiseFeedForward (:15-20), the four
+ * attention projections (:43,55,65), embeds and read-out MLPs (:270,296,340-342,400-402).
+ * x (M,K), W (N,K), b (N) or NULL, y (M,N), all fp32; act: 0 none, 1 ReLU; rowscale (M) or NULL. */
+size_t mmt_linear_workspace_bytes(int M, int K, int N);
+int mmt_linear_forward(const float* x, const float* W, const float* b, const float* rowscale, float* y,
+                       void* workspace, size_t workspace_bytes, int M, int K, int N, int act, mmt_stream_t stream);
+/* dx (M,K) or NULL; dW (N,K), db (N) or NULL.  `y` is the forward output (ReLU mask source when act==1). */
+int mmt_linear_backward(const float* dy, const float* x, const float* W, const float* y, const float* rowscale,
+                        float* dx, float* dW, float* db,
+                        void* workspace, size_t workspace_bytes, int M, int K, int N, int act, mmt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMT_HIP_H */

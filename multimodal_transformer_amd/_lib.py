@@ -1,0 +1,114 @@
+"""ctypes binding of libmmt_hip.so (include/mmt_hip.h).
+
+There is no CPU fallback: if the library cannot be loaded, or a tensor is not on a HIP
+device, the callers raise.  The library is built in-tree by ``build.py`` (hipcc, gfx950).
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmt_hip.so")
+
+_c = ctypes
+_P, _F, _I, _SZ, _U64 = _c.c_void_p, _c.c_float, _c.c_int, _c.c_size_t, _c.c_uint64
+
+# name -> (restype, argtypes); mirrors include/mmt_hip.h one to one
+SIGNATURES = {
+    "mmt_abi_version": (_I, []),
+    "mmt_last_error": (_c.c_char_p, []),
+    "mmt_encoder_param_count": (_SZ, [_I, _I, _I]),
+    "mmt_encoder_workspace_bytes": (_SZ, [_I] * 6),
+    "mmt_encoder_forward": (_I, [_P, _P, _P, _P, _P, _SZ] + [_I] * 6 + [_F, _F, _U64, _P]),
+    "mmt_encoder_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _SZ] + [_I] * 6 + [_F, _F, _U64, _P]),
+    "mmt_layernorm_scratch_floats": (_SZ, [_I, _I]),
+    "mmt_layernorm_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "mmt_layernorm_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "mmt_sdpa_workspace_bytes": (_SZ, [_I] * 4),
+    "mmt_sdpa_forward": (_I, [_P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_P]),
+    "mmt_sdpa_backward": (_I, [_P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_P]),
+    "mmt_linear_workspace_bytes": (_SZ, [_I] * 3),
+    "mmt_linear_forward": (_I, [_P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_P]),
+    "mmt_linear_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load (building first if the .so is absent and hipcc exists).  Raises RuntimeError otherwise."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            from . import build as _build
+            try:
+                _build.build(verbose=False)
+            except Exception as e:  # noqa: BLE001
+                raise RuntimeError("libmmt_hip.so is missing and could not be built with hipcc: %s" % e)
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise RuntimeError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().mmt_last_error()
+        raise RuntimeError("libmmt_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def require_hip(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("multimodal_transformer_amd runs on MI355X only: got a %s tensor; there is no CPU path "
+                               "(move the module and its inputs to a HIP device)" % t.device)
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class WorkspacePool:
+    """Zero-initialised device workspaces, reused per (device, size).
+
+    The kernels rely on pad regions of a workspace staying zero; they never write them, so a buffer
+    can be reused for the same shape without clearing.  A buffer is held by the autograd node between
+    forward and backward and handed back afterwards.
+    """
+
+    def __init__(self):
+        self._free = {}
+
+    def get(self, nbytes, device):
+        key = (str(device), int(nbytes))
+        lst = self._free.get(key)
+        if lst:
+            return lst.pop()
+        return torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+
+    def put(self, buf):
+        key = (str(buf.device), buf.numel())
+        self._free.setdefault(key, []).append(buf)
+
+    def clear(self):
+        self._free.clear()
+
+
+POOL = WorkspacePool()

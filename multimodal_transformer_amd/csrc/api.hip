@@ -1,0 +1,632 @@
+// Host side of libmmt_hip.so: workspace carving, kernel sequencing, and the extern "C" boundary
+// declared in include/mmt_hip.h.  Nothing here allocates or synchronises; everything is enqueued on
+// the caller's stream so a whole training step can be captured into one hipGraph.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include "../../include/mmt_hip.h"
+#include "common.h"
+#include "rowgemm.h"
+#include "attn.h"
+#include "misc_kernels.h"
+
+// ------------------------------------------------------------------------------------ error plumbing
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return fail(MMT_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) \
+    return fail(MMT_EHIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); } while (0)
+
+extern "C" int mmt_abi_version(void) { return 1; }
+extern "C" const char* mmt_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------ workspace carving
+struct Carver {
+    char* base; size_t off;
+    explicit Carver(void* b) : base(static_cast<char*>(b)), off(0) {}
+    template <typename T> T* take(size_t n) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += (n * sizeof(T) + 255) / 256 * 256;
+        return p;
+    }
+};
+
+static constexpr int KT_BWD = 2;            // key tiles per wave in attn_bwd (workgroup = 256 keys)
+static constexpr int MAX_LAYERS = 16;
+
+struct EncDims {
+    int B, T, d, h, f, N;
+    int M, MP, Tp, nt, G, nkb, nsplit, mchunk, M16;
+    LayerLayout L;
+};
+
+static int make_dims(EncDims& D, int B, int T, int d, int h, int f, int N) {
+    if (B <= 0 || T <= 0 || d <= 0 || h <= 0 || f <= 0 || N < 0) return fail(MMT_EINVAL, "non-positive dimension");
+    if (N > MAX_LAYERS) return fail(MMT_EUNSUPPORTED, "n_layers %d > %d", N, MAX_LAYERS);
+    if (d % h) return fail(MMT_EINVAL, "d_model %d not divisible by h %d", d, h);   // multiTransformer.py:39
+    if (d % 4 || f % 4) return fail(MMT_EUNSUPPORTED, "d_model and d_ff must be multiples of 4 (got %d, %d)", d, f);
+    if (d / h > 32) return fail(MMT_EUNSUPPORTED, "d_k = %d > 32 not supported", d / h);
+    if (d < 2) return fail(MMT_EINVAL, "d_model < 2 (unbiased std undefined)");
+    D.B = B; D.T = T; D.d = d; D.h = h; D.f = f; D.N = N;
+    D.M = B * T; D.MP = round_up(D.M, 64); D.M16 = round_up(D.M, 16);
+    D.Tp = round_up(T, 32); D.nt = D.Tp / 32; D.G = (D.M + 31) / 32;
+    D.nkb = (D.nt + 4 * KT_BWD - 1) / (4 * KT_BWD);
+    D.L = make_layout(d, f, h);
+    // weight-gradient split over windows: aim for >= 512 workgroups
+    const LayerLayout& L = D.L;
+    const int tiles = (L.NQ / 64) * (L.DP / 64) + (L.DP / 64) * (L.HDP / 64) + 2 * (L.FP / 64) * (L.DP / 64);
+    int s = (512 + tiles - 1) / tiles; if (s < 1) s = 1; if (s > 32) s = 32;
+    D.mchunk = round_up((D.M16 + s - 1) / s, 16);
+    D.nsplit = (D.M16 + D.mchunk - 1) / D.mchunk;
+    return MMT_OK;
+}
+
+struct LayerWs {
+    float *xout, *x1, *stats1, *stats2, *lse;
+    bf16 *xn1T, *xn2T, *QR, *KR, *VR, *QT, *KT, *VT, *ctx, *ctxT, *hid, *hidT;
+};
+struct EncWs {
+    bf16* wprep; float* bprep; float* statsf;
+    LayerWs lw[MAX_LAYERS];
+    // backward scratch (shared by all layers; single stream)
+    float *dxa, *dxb, *delta, *dqslab, *lnpart1, *lnpart2;
+    bf16 *dx2T, *dh, *dhT, *dx1T, *dOR, *dOT, *dqkv, *dqkvT;
+    float *sWqkv, *sbqkv, *sWo, *sbo, *sW1, *sb1, *sW2, *sb2;
+    size_t bytes;
+};
+
+static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
+    Carver c(base);
+    const LayerLayout& L = D.L;
+    const size_t M = D.M, MP = D.MP, BH = (size_t)D.B * D.h;
+    W.wprep = c.take<bf16>(L.pstride() * (size_t)(D.N > 0 ? D.N : 1));
+    W.bprep = c.take<float>(L.qstride() * (size_t)(D.N > 0 ? D.N : 1));
+    W.statsf = c.take<float>(2 * M);
+    for (int l = 0; l < D.N; ++l) {
+        LayerWs& w = W.lw[l];
+        w.xout = c.take<float>(M * D.d); w.x1 = c.take<float>(M * D.d);
+        w.stats1 = c.take<float>(2 * M); w.stats2 = c.take<float>(2 * M);
+        w.lse = c.take<float>(BH * D.Tp);
+        w.xn1T = c.take<bf16>((size_t)L.DP * MP); w.xn2T = c.take<bf16>((size_t)L.DP * MP);
+        w.QR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); w.KR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP));
+        w.VR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP));
+        w.QT = c.take<bf16>(BH * fragT_elems(D.Tp)); w.KT = c.take<bf16>(BH * fragT_elems(D.Tp));
+        w.VT = c.take<bf16>(BH * fragT_elems(D.Tp));
+        w.ctx = c.take<bf16>(M * L.HDP); w.ctxT = c.take<bf16>((size_t)L.HDP * MP);
+        w.hid = c.take<bf16>(M * L.FP); w.hidT = c.take<bf16>((size_t)L.FP * MP);
+    }
+    W.dxa = c.take<float>(M * D.d); W.dxb = c.take<float>(M * D.d);
+    W.delta = c.take<float>(BH * D.Tp);
+    W.dqslab = c.take<float>((size_t)D.nkb * M * L.HDP);
+    W.lnpart1 = c.take<float>((size_t)D.G * 2 * L.DP); W.lnpart2 = c.take<float>((size_t)D.G * 2 * L.DP);
+    W.dx2T = c.take<bf16>((size_t)L.DP * MP); W.dh = c.take<bf16>(M * L.FP); W.dhT = c.take<bf16>((size_t)L.FP * MP);
+    W.dx1T = c.take<bf16>((size_t)L.DP * MP);
+    W.dOR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); W.dOT = c.take<bf16>(BH * fragT_elems(D.Tp));
+    W.dqkv = c.take<bf16>(M * L.NQ); W.dqkvT = c.take<bf16>((size_t)L.NQ * MP);
+    const size_t S = D.nsplit;
+    W.sWqkv = c.take<float>(S * L.NQ * L.DP); W.sbqkv = c.take<float>(S * L.NQ);
+    W.sWo = c.take<float>(S * L.DP * L.HDP); W.sbo = c.take<float>(S * L.DP);
+    W.sW1 = c.take<float>(S * L.FP * L.DP); W.sb1 = c.take<float>(S * L.FP);
+    W.sW2 = c.take<float>(S * L.DP * L.FP); W.sb2 = c.take<float>(S * L.DP);
+    W.bytes = c.off;
+}
+
+// ------------------------------------------------------------------------------------ launch helpers
+template <int EPI, bool LN>
+static int launch_rowgemm(const RowGemmParams& p, hipStream_t st) {
+    const size_t lds = rowgemm_lds_bytes(EPI, LN, p.KP, p.NP);
+    if (lds > 160 * 1024) return fail(MMT_EUNSUPPORTED, "row GEMM tile needs %zu B of LDS (K=%d, N=%d)", lds, p.K, p.N);
+    static size_t configured = 0;           // per instantiation
+    if (lds > configured) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<EPI, LN>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = 160 * 1024;
+    }
+    const int grid = (p.M + 31) / 32;
+    hipLaunchKernelGGL((rowgemm_kernel<EPI, LN>), dim3(grid), dim3(MMT_THREADS), lds, st, p);
+    LAUNCH_CHECK("rowgemm_kernel");
+    return MMT_OK;
+}
+
+static RowGemmParams rg_zero() { RowGemmParams p; memset(&p, 0, sizeof(p)); return p; }
+
+static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* VT, bf16* ctx, bf16* ctxT, float* lse,
+                           const EncDims& D, hipStream_t st) {
+    dim3 grid((D.nt + 3) / 4, D.B * D.h);
+    if (DKP == 16) hipLaunchKernelGGL((attn_fwd_kernel<16>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, D.h, D.T, D.nt, D.L.HDP, D.MP);
+    else hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, D.h, D.T, D.nt, D.L.HDP, D.MP);
+    LAUNCH_CHECK("attn_fwd_kernel");
+    return MMT_OK;
+}
+
+static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* KR, const bf16* KT_, const bf16* VR,
+                           const bf16* dOR, const bf16* dOT, const float* lse, const float* delta, float* dqslab,
+                           bf16* dkv, bf16* dkvT, const EncDims& D, hipStream_t st) {
+    dim3 grid(D.nkb, D.B * D.h);
+    if (DKP == 16)
+        hipLaunchKernelGGL((attn_bwd_kernel<16, KT_BWD>), grid, dim3(MMT_THREADS), 0, st, QR, QT, KR, KT_, VR, dOR, dOT, lse, delta,
+                           dqslab, dkv, D.L.NQ, dkvT, D.MP, D.h, D.T, D.nt, D.M, D.L.HDP);
+    else
+        hipLaunchKernelGGL((attn_bwd_kernel<32, KT_BWD>), grid, dim3(MMT_THREADS), 0, st, QR, QT, KR, KT_, VR, dOR, dOT, lse, delta,
+                           dqslab, dkv, D.L.NQ, dkvT, D.MP, D.h, D.T, D.nt, D.M, D.L.HDP);
+    LAUNCH_CHECK("attn_bwd_kernel");
+    return MMT_OK;
+}
+
+static int grid_for(size_t n, int block = 256) {
+    size_t g = (n + block - 1) / block;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------ encoder stack
+extern "C" size_t mmt_encoder_param_count(int d, int f, int n_layers) {
+    LayerLayout L = make_layout(d, f, 1);
+    return L.stride() * (size_t)n_layers + 2 * (size_t)d;
+}
+
+extern "C" size_t mmt_encoder_workspace_bytes(int B, int T, int d, int h, int f, int n_layers) {
+    EncDims D;
+    if (make_dims(D, B, T, d, h, f, n_layers) != MMT_OK) return 0;
+    EncWs W; carve_encoder(W, D, nullptr);
+    return W.bytes;
+}
+
+static const float LOG2E = 1.4426950408889634f;
+
+extern "C" int mmt_encoder_forward(const float* x, const float* mask, const float* params, float* y,
+                                   void* workspace, size_t workspace_bytes,
+                                   int B, int T, int d, int h, int f, int n_layers, float eps,
+                                   float dropout_p, uint64_t seed, mmt_stream_t stream) {
+    (void)seed;
+    EncDims D;
+    int rc = make_dims(D, B, T, d, h, f, n_layers);
+    if (rc) return rc;
+    if (!x || !mask || !params || !y || !workspace) return fail(MMT_EINVAL, "null pointer argument");
+    if (dropout_p != 0.f) return fail(MMT_EUNSUPPORTED, "train-mode dropout is not implemented yet (dropout_p must be 0)");
+    EncWs W; carve_encoder(W, D, workspace);
+    if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const LayerLayout& L = D.L;
+
+    if (D.N > 0) {
+        hipLaunchKernelGGL(encoder_prep_kernel, dim3(grid_for(L.pstride() + L.qstride()), D.N), dim3(256), 0, st,
+                           params, W.wprep, W.bprep, L);
+        LAUNCH_CHECK("encoder_prep_kernel");
+    }
+    const float* xin = x;
+    for (int l = 0; l < D.N; ++l) {
+        const LayerWs& w = W.lw[l];
+        const float* P = params + (size_t)l * L.stride();
+        const bf16* wp = W.wprep + (size_t)l * L.pstride();
+        const float* bp = W.bprep + (size_t)l * L.qstride();
+        {   // LayerNorm 1 + fused Q/K/V projection -> attention operand fragments
+            RowGemmParams p = rg_zero();
+            p.M = D.M; p.K = d; p.KP = L.DP; p.N = 3 * L.HD; p.NP = L.NQ;
+            p.A = xin; p.lda = d; p.At_out = w.xn1T; p.ldt = D.MP;
+            p.ln_a = P + L.oln(0); p.ln_b = P + L.oln(1); p.eps = eps; p.stats = w.stats1;
+            p.W = wp + L.pWqkv(); p.bias = bp + L.qbqkv();
+            p.fragR[0] = w.QR; p.fragR[1] = w.KR; p.fragR[2] = w.VR;
+            p.fragT[0] = w.QT; p.fragT[1] = w.KT; p.fragT[2] = w.VT;
+            p.T = T; p.Tp = D.Tp; p.h = h; p.DKP = L.DKP; p.nwhich = 3;
+            p.rowmask = mask; p.qscale = LOG2E / sqrtf((float)L.dk); p.scale_first = 1;
+            if ((rc = launch_rowgemm<EPI_FRAG, true>(p, st))) return rc;
+        }
+        if ((rc = launch_attn_fwd(L.DKP, w.QR, w.KR, w.VT, w.ctx, w.ctxT, w.lse, D, st))) return rc;
+        {   // output projection + residual
+            RowGemmParams p = rg_zero();
+            p.M = D.M; p.K = L.HDP; p.KP = L.HDP; p.N = d; p.NP = L.DP;
+            p.A = w.ctx; p.a_bf16 = 1; p.lda = L.HDP;
+            p.W = wp + L.pWo(); p.bias = bp + L.qbo();
+            p.residual = xin; p.ldr = d; p.out_f32 = w.x1; p.ldo = d;
+            if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st))) return rc;
+        }
+        {   // LayerNorm 2 + first FFN product + ReLU
+            RowGemmParams p = rg_zero();
+            p.M = D.M; p.K = d; p.KP = L.DP; p.N = f; p.NP = L.FP;
+            p.A = w.x1; p.lda = d; p.At_out = w.xn2T; p.ldt = D.MP;
+            p.ln_a = P + L.oln(2); p.ln_b = P + L.oln(3); p.eps = eps; p.stats = w.stats2;
+            p.W = wp + L.pW1(); p.bias = bp + L.qb1(); p.act = 1;
+            p.out_bf16 = w.hid; p.ldo16 = L.FP; p.n_store16 = L.FP; p.out_T = w.hidT; p.ldoT = D.MP;
+            if ((rc = launch_rowgemm<EPI_PLAIN, true>(p, st))) return rc;
+        }
+        {   // second FFN product + residual
+            RowGemmParams p = rg_zero();
+            p.M = D.M; p.K = L.FP; p.KP = L.FP; p.N = d; p.NP = L.DP;
+            p.A = w.hid; p.a_bf16 = 1; p.lda = L.FP;
+            p.W = wp + L.pW2(); p.bias = bp + L.qb2();
+            p.residual = w.x1; p.ldr = d; p.out_f32 = w.xout; p.ldo = d;
+            if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st))) return rc;
+        }
+        xin = w.xout;
+    }
+    const float* Pf = params + (size_t)D.N * L.stride();
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(D.G), dim3(MMT_THREADS), 0, st, xin, Pf, Pf + d, eps, y, W.statsf, D.M, d);
+    LAUNCH_CHECK("layernorm_fwd_kernel");
+    return MMT_OK;
+}
+
+static int launch_ln_bwd(const float* dy, const float* x, const float* a, const float* stats, float eps, float* dx,
+                         float* colpart, int M, int d, int DP, hipStream_t st) {
+    const size_t lds = (size_t)2 * 32 * (DP + 4) * 4;
+    static bool configured = false;
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&layernorm_bwd_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    if (lds > 160 * 1024) return fail(MMT_EUNSUPPORTED, "LayerNorm width %d too large", d);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + 31) / 32), dim3(MMT_THREADS), lds, st, dy, x, a, stats, eps, dx, colpart, M, d, DP);
+    LAUNCH_CHECK("layernorm_bwd_kernel");
+    return MMT_OK;
+}
+
+extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float* mask, const float* params,
+                                    float* dx, float* dparams,
+                                    void* workspace, size_t workspace_bytes,
+                                    int B, int T, int d, int h, int f, int n_layers, float eps,
+                                    float dropout_p, uint64_t seed, mmt_stream_t stream) {
+    (void)seed;
+    EncDims D;
+    int rc = make_dims(D, B, T, d, h, f, n_layers);
+    if (rc) return rc;
+    if (!dy || !x || !mask || !params || !dx || !dparams || !workspace) return fail(MMT_EINVAL, "null pointer argument");
+    if (dropout_p != 0.f) return fail(MMT_EUNSUPPORTED, "train-mode dropout is not implemented yet (dropout_p must be 0)");
+    EncWs W; carve_encoder(W, D, workspace);
+    if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const LayerLayout& L = D.L;
+
+    // final LayerNorm
+    const float* Pf = params + (size_t)D.N * L.stride();
+    float* gPf = dparams + (size_t)D.N * L.stride();
+    const float* x_last = (D.N > 0) ? W.lw[D.N - 1].xout : x;
+    float* cur = (D.N > 0) ? W.dxa : dx;
+    if ((rc = launch_ln_bwd(dy, x_last, Pf, W.statsf, eps, cur, W.lnpart1, D.M, d, L.DP, st))) return rc;
+    hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, st, W.lnpart1, D.G, L.DP, d, gPf, gPf + d);
+    LAUNCH_CHECK("ln_param_finalize_kernel");
+
+    float* other = W.dxb;
+    for (int l = D.N - 1; l >= 0; --l) {
+        const LayerWs& w = W.lw[l];
+        const float* P = params + (size_t)l * L.stride();
+        float* gP = dparams + (size_t)l * L.stride();
+        const bf16* wp = W.wprep + (size_t)l * L.pstride();
+        const float* xin = (l > 0) ? W.lw[l - 1].xout : x;
+        {   // dh = (dx2 W2) * relu'(hid)          [also emits dx2^T for dW2]
+            RowGemmParams p = rg_zero();
+            p.M = D.M; p.K = d; p.KP = L.DP; p.N = f; p.NP = L.FP;
+            p.A = cur; p.lda = d; p.At_out = W.dx2T; p.ldt = D.MP;
+            p.W = wp + L.pW2T();
+            p.relu_mask = w.hid; p.ldm = L.FP;
+            p.out_bf16 = W.dh; p.ldo16 = L.FP; p.n_store16 = L.FP; p.out_T = W.dhT; p.ldoT = D.MP;
+            if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st))) return rc;
+        }
+        {   // dx1 = dx2 + LN2bwd(dh W1)
+            RowGemmParams p = rg_zero();
+            p.M = D.M; p.K = L.FP; p.KP = L.FP; p.N = d; p.NP = L.DP;
+            p.A = W.dh; p.a_bf16 = 1; p.lda = L.FP;
+            p.W = wp + L.pW1T();
+            p.x = w.x1; p.ldx = d; p.st = w.stats2; p.ln_a = P + L.oln(2); p.eps = eps; p.d_real = d;
+            p.dres = cur; p.lddres = d; p.out_f32 = other; p.ldo = d; p.colpart = W.lnpart2;
+            if ((rc = launch_rowgemm<EPI_LNBWD, false>(p, st))) return rc;
+        }
+        {   // dO = dx1 Wo -> fragments + delta     [also emits dx1^T for dWo]
+            RowGemmParams p = rg_zero();
+            p.M = D.M; p.K = d; p.KP = L.DP; p.N = L.HD; p.NP = L.HDP;
+            p.A = other; p.lda = d; p.At_out = W.dx1T; p.ldt = D.MP;
+            p.W = wp + L.pWoT();
+            p.fragR[0] = W.dOR; p.fragT[0] = W.dOT;
+            p.T = T; p.Tp = D.Tp; p.h = h; p.DKP = L.DKP; p.nwhich = 1;
+            p.ctx = w.ctx; p.ldctx = L.HDP; p.delta = W.delta;
+            if ((rc = launch_rowgemm<EPI_FRAG, false>(p, st))) return rc;
+        }
+        if ((rc = launch_attn_bwd(L.DKP, w.QR, w.QT, w.KR, w.KT, w.VR, W.dOR, W.dOT, w.lse, W.delta, W.dqslab,
+                                  W.dqkv, W.dqkvT, D, st))) return rc;
+        hipLaunchKernelGGL(dq_finish_kernel, dim3(grid_for((size_t)D.M * L.HD / 4)), dim3(256), 0, st,
+                           W.dqslab, D.nkb, mask, 1.0f / sqrtf((float)L.dk), W.dqkv, L.NQ, W.dqkvT, D.MP, D.M, L.HD, L.HDP);
+        LAUNCH_CHECK("dq_finish_kernel");
+        float* dxin = (l > 0) ? cur : dx;
+        {   // dx = dx1 + LN1bwd(dQKV Wqkv)
+            RowGemmParams p = rg_zero();
+            p.M = D.M; p.K = L.NQ; p.KP = L.NQ; p.N = d; p.NP = L.DP;
+            p.A = W.dqkv; p.a_bf16 = 1; p.lda = L.NQ;
+            p.W = wp + L.pWqkvT();
+            p.x = xin; p.ldx = d; p.st = w.stats1; p.ln_a = P + L.oln(0); p.eps = eps; p.d_real = d;
+            p.dres = other; p.lddres = d; p.out_f32 = dxin; p.ldo = d; p.colpart = W.lnpart1;
+            if ((rc = launch_rowgemm<EPI_LNBWD, false>(p, st))) return rc;
+        }
+        {   // weight gradients of the layer
+            WgradJobs J; memset(&J, 0, sizeof(J));
+            J.njobs = 4; J.MP = D.MP; J.M16 = D.M16; J.mchunk = D.mchunk;
+            int t0 = 0;
+            auto add = [&](int i, const bf16* At, const bf16* Bt, float* out, float* bout, int NPj, int KPj) {
+                J.j[i].At = At; J.j[i].Bt = Bt; J.j[i].out = out; J.j[i].bias_out = bout;
+                J.j[i].NPj = NPj; J.j[i].KPj = KPj; J.j[i].tile0 = t0; J.j[i].tiles_k = KPj / 64;
+                t0 += (NPj / 64) * (KPj / 64);
+            };
+            add(0, W.dqkvT, w.xn1T, W.sWqkv, W.sbqkv, L.NQ, L.DP);
+            add(1, W.dx1T, w.ctxT, W.sWo, W.sbo, L.DP, L.HDP);
+            add(2, W.dhT, w.xn2T, W.sW1, W.sb1, L.FP, L.DP);
+            add(3, W.dx2T, w.hidT, W.sW2, W.sb2, L.DP, L.FP);
+            hipLaunchKernelGGL(wgrad_kernel, dim3(t0, D.nsplit), dim3(MMT_THREADS), 0, st, J);
+            LAUNCH_CHECK("wgrad_kernel");
+            LayerSlabs S;
+            S.dWqkv = W.sWqkv; S.dbqkv = W.sbqkv; S.dWo = W.sWo; S.dbo = W.sbo;
+            S.dW1 = W.sW1; S.db1 = W.sb1; S.dW2 = W.sW2; S.db2 = W.sb2;
+            S.ln1part = W.lnpart1; S.ln2part = W.lnpart2; S.nsplit = D.nsplit; S.G = D.G;
+            hipLaunchKernelGGL(encoder_finalize_kernel, dim3(grid_for(L.oln(0))), dim3(256), 0, st, S, L, gP);
+            LAUNCH_CHECK("encoder_finalize_kernel");
+            hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, st, W.lnpart1, D.G, L.DP, d,
+                               gP + L.oln(0), gP + L.oln(1));
+            hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, st, W.lnpart2, D.G, L.DP, d,
+                               gP + L.oln(2), gP + L.oln(3));
+            LAUNCH_CHECK("ln_param_finalize_kernel");
+        }
+        // cur now holds dx of this layer (= dx2 of the layer below); `other` is free again
+    }
+    return MMT_OK;
+}
+
+// ------------------------------------------------------------------------------------ LayerNorm alone
+extern "C" size_t mmt_layernorm_scratch_floats(int M, int d) {
+    return (size_t)((M + 31) / 32) * 2 * round_up(d, 64);
+}
+
+extern "C" int mmt_layernorm_forward(const float* x, const float* a_2, const float* b_2, float* y, float* stats,
+                                     int M, int d, float eps, mmt_stream_t stream) {
+    if (!x || !a_2 || !b_2 || !y) return fail(MMT_EINVAL, "null pointer argument");
+    if (M <= 0 || d < 2) return fail(MMT_EINVAL, "bad shape M=%d d=%d", M, d);
+    if (d % 4) return fail(MMT_EUNSUPPORTED, "feature count %d must be a multiple of 4", d);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((M + 31) / 32), dim3(MMT_THREADS), 0, static_cast<hipStream_t>(stream),
+                       x, a_2, b_2, eps, y, stats, M, d);
+    LAUNCH_CHECK("layernorm_fwd_kernel");
+    return MMT_OK;
+}
+
+extern "C" int mmt_layernorm_backward(const float* dy, const float* x, const float* a_2, const float* stats,
+                                      float* dx, float* da_2, float* db_2, float* scratch,
+                                      int M, int d, float eps, mmt_stream_t stream) {
+    if (!dy || !x || !a_2 || !stats || !dx || !da_2 || !db_2 || !scratch) return fail(MMT_EINVAL, "null pointer argument");
+    if (M <= 0 || d < 2) return fail(MMT_EINVAL, "bad shape M=%d d=%d", M, d);
+    if (d % 4) return fail(MMT_EUNSUPPORTED, "feature count %d must be a multiple of 4", d);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int DP = round_up(d, 64), G = (M + 31) / 32;
+    int rc = launch_ln_bwd(dy, x, a_2, stats, eps, dx, scratch, M, d, DP, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, st, scratch, G, DP, d, da_2, db_2);
+    LAUNCH_CHECK("ln_param_finalize_kernel");
+    return MMT_OK;
+}
+
+// ------------------------------------------------------------------------------------ attention core alone
+// pack (B,T,d) fp32 head-major-column tensors into fragment layouts; unpack head-padded bf16 back.
+__global__ void pack_frag_kernel(const float* __restrict__ src, bf16* __restrict__ fr, bf16* __restrict__ ft,
+                                 const float* __restrict__ rowmask, float scale, int use_mask,
+                                 const bf16* __restrict__ ctx, int ldctx, float* __restrict__ delta,
+                                 int M, int T, int Tp, int h, int dk, int DKP, int d) {
+    const size_t total = (size_t)M * h;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / h), head = (int)(idx % h), b = m / T, t = m - b * T;
+        const size_t bh = (size_t)b * h + head;
+        float sc = scale;
+        if (use_mask && rowmask && rowmask[m] == 0.0f) sc = 0.f;
+        float part = 0.f;
+        for (int e = 0; e < dk; ++e) {
+            const bf16 v = (bf16)(src[(size_t)m * d + head * dk + e] * sc);
+            fr[bh * fragR_elems(Tp, DKP) + fragR_index(t, e, DKP)] = v;
+            ft[bh * fragT_elems(Tp) + fragT_index(t, e)] = v;
+            if (delta) part += (float)v * (float)ctx[(size_t)m * ldctx + head * DKP + e];
+        }
+        if (delta) delta[bh * Tp + t] = part;
+    }
+}
+
+__global__ void unpad_heads_kernel(const bf16* __restrict__ src, int ld, int col0, float* __restrict__ dst,
+                                   int M, int h, int dk, int DKP, int d) {
+    const size_t total = (size_t)M * d;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / d), c = (int)(idx % d), head = c / dk, e = c - head * dk;
+        dst[idx] = (float)src[(size_t)m * ld + col0 + head * DKP + e];
+    }
+}
+
+struct SdpaWs { bf16 *QR, *QT, *KR, *KT, *VR, *VT, *dOR, *dOT, *ctx, *ctxT, *dqkv, *dqkvT; float *lse, *delta, *dqslab; size_t bytes; };
+static void carve_sdpa(SdpaWs& W, const EncDims& D, void* base) {
+    Carver c(base);
+    const LayerLayout& L = D.L;
+    const size_t BH = (size_t)D.B * D.h, M = D.M;
+    bf16** r[] = {&W.QR, &W.KR, &W.VR, &W.dOR};
+    bf16** t[] = {&W.QT, &W.KT, &W.VT, &W.dOT};
+    for (int i = 0; i < 4; ++i) { *r[i] = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); *t[i] = c.take<bf16>(BH * fragT_elems(D.Tp)); }
+    W.ctx = c.take<bf16>(M * L.HDP); W.ctxT = c.take<bf16>((size_t)L.HDP * D.MP);
+    W.dqkv = c.take<bf16>(M * L.NQ); W.dqkvT = c.take<bf16>((size_t)L.NQ * D.MP);
+    W.lse = c.take<float>(BH * D.Tp); W.delta = c.take<float>(BH * D.Tp);
+    W.dqslab = c.take<float>((size_t)D.nkb * M * L.HDP);
+    W.bytes = c.off;
+}
+
+extern "C" size_t mmt_sdpa_workspace_bytes(int B, int T, int d, int h) {
+    EncDims D;
+    if (make_dims(D, B, T, d, h, 4, 0) != MMT_OK) return 0;
+    SdpaWs W; carve_sdpa(W, D, nullptr);
+    return W.bytes;
+}
+
+extern "C" int mmt_sdpa_forward(const float* q, const float* k, const float* v, const float* mask, float* ctx,
+                                void* workspace, size_t workspace_bytes, int B, int T, int d, int h, mmt_stream_t stream) {
+    EncDims D;
+    int rc = make_dims(D, B, T, d, h, 4, 0);
+    if (rc) return rc;
+    if (!q || !k || !v || !ctx || !workspace) return fail(MMT_EINVAL, "null pointer argument");
+    SdpaWs W; carve_sdpa(W, D, workspace);
+    if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const LayerLayout& L = D.L;
+    const int g = grid_for((size_t)D.M * h);
+    const float qs = LOG2E / sqrtf((float)L.dk);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, q, W.QR, W.QT, mask, qs, 1, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, k, W.KR, W.KT, nullptr, 1.f, 0, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, v, W.VR, W.VT, nullptr, 1.f, 0, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
+    LAUNCH_CHECK("pack_frag_kernel");
+    if ((rc = launch_attn_fwd(L.DKP, W.QR, W.KR, W.VT, W.ctx, W.ctxT, W.lse, D, st))) return rc;
+    hipLaunchKernelGGL(unpad_heads_kernel, dim3(grid_for((size_t)D.M * d)), dim3(256), 0, st, W.ctx, L.HDP, 0, ctx, D.M, h, L.dk, L.DKP, d);
+    LAUNCH_CHECK("unpad_heads_kernel");
+    return MMT_OK;
+}
+
+extern "C" int mmt_sdpa_backward(const float* dctx, const float* mask, float* dq, float* dk, float* dv,
+                                 void* workspace, size_t workspace_bytes, int B, int T, int d, int h, mmt_stream_t stream) {
+    EncDims D;
+    int rc = make_dims(D, B, T, d, h, 4, 0);
+    if (rc) return rc;
+    if (!dctx || !dq || !dk || !dv || !workspace) return fail(MMT_EINVAL, "null pointer argument");
+    SdpaWs W; carve_sdpa(W, D, workspace);
+    if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const LayerLayout& L = D.L;
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(grid_for((size_t)D.M * h)), dim3(256), 0, st, dctx, W.dOR, W.dOT, nullptr, 1.f, 0,
+                       W.ctx, L.HDP, W.delta, D.M, T, D.Tp, h, L.dk, L.DKP, d);
+    LAUNCH_CHECK("pack_frag_kernel");
+    if ((rc = launch_attn_bwd(L.DKP, W.QR, W.QT, W.KR, W.KT, W.VR, W.dOR, W.dOT, W.lse, W.delta, W.dqslab, W.dqkv, W.dqkvT, D, st))) return rc;
+    // the pack above stored Q' = q*log2e/sqrt(dk); gradient wrt the caller's q needs the same factor folded as in
+    // the fused path: dq = (dS K)/sqrt(dk); a NULL mask blanks nothing
+    hipLaunchKernelGGL(dq_finish_kernel, dim3(grid_for((size_t)D.M * L.HD / 4)), dim3(256), 0, st, W.dqslab, D.nkb,
+                       mask, 1.0f / sqrtf((float)L.dk), W.dqkv, L.NQ, W.dqkvT, D.MP, D.M, L.HD, L.HDP);
+    LAUNCH_CHECK("dq_finish_kernel");
+    const int g = grid_for((size_t)D.M * d);
+    hipLaunchKernelGGL(unpad_heads_kernel, dim3(g), dim3(256), 0, st, W.dqkv, L.NQ, 0, dq, D.M, h, L.dk, L.DKP, d);
+    hipLaunchKernelGGL(unpad_heads_kernel, dim3(g), dim3(256), 0, st, W.dqkv, L.NQ, L.HD, dk, D.M, h, L.dk, L.DKP, d);
+    hipLaunchKernelGGL(unpad_heads_kernel, dim3(g), dim3(256), 0, st, W.dqkv, L.NQ, 2 * L.HD, dv, D.M, h, L.dk, L.DKP, d);
+    LAUNCH_CHECK("unpad_heads_kernel");
+    return MMT_OK;
+}
+
+// ------------------------------------------------------------------------------------ fused affine map alone
+__global__ void pad_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int np) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) dst[i] = (i < n && src) ? src[i] : 0.f;
+}
+
+// g = dy * rowscale * relu'(y) -> bf16 row-major [M][NP] and T layout [NP][MP]
+__global__ void grad_prep_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ rowscale,
+                                 int act, bf16* __restrict__ g, bf16* __restrict__ gT, int M, int N, int NP, int MP) {
+    const size_t total = (size_t)M * NP;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / NP), n = (int)(idx % NP);
+        float v = 0.f;
+        if (n < N) {
+            v = dy[(size_t)m * N + n];
+            if (rowscale) v *= rowscale[m];
+            if (act == 1 && !(y[(size_t)m * N + n] > 0.f)) v = 0.f;
+        }
+        const bf16 o = (bf16)v;
+        g[idx] = o;
+        gT[(size_t)n * MP + m] = o;
+    }
+}
+
+// fp32 [M][K] -> bf16 T layout [KP][MP] (rows k >= K are written as zeros for m < M)
+__global__ void transpose_cast_kernel(const float* __restrict__ src, bf16* __restrict__ dstT, int M, int K, int KP, int MP) {
+    __shared__ float tile[32][33];
+    const int m0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 8 rows per pass
+    for (int r = ty; r < 32; r += 8) {
+        const int m = m0 + r, k = k0 + tx;
+        tile[r][tx] = (m < M && k < K) ? src[(size_t)m * K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, m = m0 + tx;
+        if (k < KP && m < M) dstT[(size_t)k * MP + m] = (bf16)tile[tx][r];
+    }
+}
+
+struct LinWs { bf16 *Wp, *WTp, *g, *gT, *xT; float *bp, *sW, *sb; int KP, NP, MP, M16, nsplit, mchunk; size_t bytes; };
+static void carve_linear(LinWs& W, int M, int K, int N, void* base) {
+    Carver c(base);
+    W.KP = round_up(K, 64); W.NP = round_up(N, 64); W.MP = round_up(M, 64); W.M16 = round_up(M, 16);
+    const int tiles = (W.NP / 64) * (W.KP / 64);
+    int s = (512 + tiles - 1) / tiles; if (s < 1) s = 1; if (s > 32) s = 32;
+    W.mchunk = round_up((W.M16 + s - 1) / s, 16);
+    W.nsplit = (W.M16 + W.mchunk - 1) / W.mchunk;
+    W.Wp = c.take<bf16>((size_t)W.NP * W.KP); W.WTp = c.take<bf16>((size_t)W.KP * W.NP);
+    W.bp = c.take<float>(W.NP);
+    W.g = c.take<bf16>((size_t)M * W.NP); W.gT = c.take<bf16>((size_t)W.NP * W.MP); W.xT = c.take<bf16>((size_t)W.KP * W.MP);
+    W.sW = c.take<float>((size_t)W.nsplit * W.NP * W.KP); W.sb = c.take<float>((size_t)W.nsplit * W.NP);
+    W.bytes = c.off;
+}
+
+extern "C" size_t mmt_linear_workspace_bytes(int M, int K, int N) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    LinWs W; carve_linear(W, M, K, N, nullptr);
+    return W.bytes;
+}
+
+static int check_linear(int M, int K, int N) {
+    if (M <= 0 || K <= 0 || N <= 0) return fail(MMT_EINVAL, "bad shape M=%d K=%d N=%d", M, K, N);
+    if (K % 4) return fail(MMT_EUNSUPPORTED, "in_features %d must be a multiple of 4", K);
+    return MMT_OK;
+}
+
+extern "C" int mmt_linear_forward(const float* x, const float* Wt, const float* b, const float* rowscale, float* y,
+                                  void* workspace, size_t workspace_bytes, int M, int K, int N, int act, mmt_stream_t stream) {
+    int rc = check_linear(M, K, N);
+    if (rc) return rc;
+    if (!x || !Wt || !y || !workspace) return fail(MMT_EINVAL, "null pointer argument");
+    LinWs W; carve_linear(W, M, K, N, workspace);
+    if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(pad_cast_kernel, dim3(grid_for((size_t)W.NP * W.KP)), dim3(256), 0, st, Wt, W.Wp, N, K, W.NP, W.KP, 0);
+    hipLaunchKernelGGL(pad_f32_kernel, dim3((W.NP + 255) / 256), dim3(256), 0, st, b, W.bp, N, W.NP);
+    LAUNCH_CHECK("pad_cast_kernel");
+    RowGemmParams p = rg_zero();
+    p.M = M; p.K = K; p.KP = W.KP; p.N = N; p.NP = W.NP;
+    p.A = x; p.lda = K; p.W = W.Wp; p.bias = W.bp; p.act = act; p.rowscale = rowscale;
+    p.out_f32 = y; p.ldo = N;
+    return launch_rowgemm<EPI_PLAIN, false>(p, st);
+}
+
+extern "C" int mmt_linear_backward(const float* dy, const float* x, const float* Wt, const float* y, const float* rowscale,
+                                   float* dx, float* dW, float* db,
+                                   void* workspace, size_t workspace_bytes, int M, int K, int N, int act, mmt_stream_t stream) {
+    int rc = check_linear(M, K, N);
+    if (rc) return rc;
+    if (!dy || !x || !Wt || !workspace || (act == 1 && !y)) return fail(MMT_EINVAL, "null pointer argument");
+    LinWs W; carve_linear(W, M, K, N, workspace);
+    if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(grad_prep_kernel, dim3(grid_for((size_t)M * W.NP)), dim3(256), 0, st, dy, y, rowscale, act, W.g, W.gT, M, N, W.NP, W.MP);
+    LAUNCH_CHECK("grad_prep_kernel");
+    if (dx) {
+        hipLaunchKernelGGL(pad_cast_kernel, dim3(grid_for((size_t)W.KP * W.NP)), dim3(256), 0, st, Wt, W.WTp, K, N, W.KP, W.NP, 1);
+        LAUNCH_CHECK("pad_cast_kernel");
+        RowGemmParams p = rg_zero();
+        p.M = M; p.K = W.NP; p.KP = W.NP; p.N = K; p.NP = W.KP;
+        p.A = W.g; p.a_bf16 = 1; p.lda = W.NP; p.W = W.WTp;
+        p.out_f32 = dx; p.ldo = K;
+        if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st))) return rc;
+    }
+    if (dW || db) {
+        hipLaunchKernelGGL(transpose_cast_kernel, dim3((M + 31) / 32, W.KP / 32), dim3(256), 0, st, x, W.xT, M, K, W.KP, W.MP);
+        LAUNCH_CHECK("transpose_cast_kernel");
+        WgradJobs J; memset(&J, 0, sizeof(J));
+        J.njobs = 1; J.MP = W.MP; J.M16 = W.M16; J.mchunk = W.mchunk;
+        J.j[0].At = W.gT; J.j[0].Bt = W.xT; J.j[0].out = W.sW; J.j[0].bias_out = W.sb;
+        J.j[0].NPj = W.NP; J.j[0].KPj = W.KP; J.j[0].tile0 = 0; J.j[0].tiles_k = W.KP / 64;
+        hipLaunchKernelGGL(wgrad_kernel, dim3((W.NP / 64) * (W.KP / 64), W.nsplit), dim3(MMT_THREADS), 0, st, J);
+        LAUNCH_CHECK("wgrad_kernel");
+        if (dW) hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for((size_t)N * K)), dim3(256), 0, st, W.sW, W.nsplit, W.NP, W.KP, dW, N, K);
+        if (db) hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for((size_t)N)), dim3(256), 0, st, W.sb, W.nsplit, 1, W.NP, db, 1, N);
+        LAUNCH_CHECK("slab_sum_kernel");
+    }
+    return MMT_OK;
+}

@@ -1,0 +1,79 @@
+// Shared device-side definitions for the gfx950 (MI355X / CDNA4) kernels.
+//
+// Conventions used by every kernel in this directory
+// ---------------------------------------------------
+//  * wavefront = 64 lanes; workgroups are 256 threads (4 waves, one per SIMD) unless stated.
+//  * matrix products run on bf16 MFMA with fp32 accumulation; the residual stream, LayerNorm
+//    statistics, softmax and every reduction stay fp32.
+//  * "row-major [M][ld]" tensors are indexed by the flattened window index m = b*T + t.
+//  * "T layout" = feature-major copy [feature][MP] (MP = M rounded up to 64, pad columns are zero and
+//    never written) — the operand form the weight-gradient kernel contracts over m.
+//  * attention operands live in two per-(batch,head) *fragment* layouts, chosen so that every MFMA
+//    operand fragment is one lane-linear 16-byte load (1 KiB per wave instruction):
+//      R layout  [tile][e>>3][t&31][e&7]          contraction over the head feature e
+//      T layout  [tile][s][hh][e (32 rows)][j]    contraction over the 32 windows of a tile, in the
+//                 order an MFMA 32x32 accumulator presents its rows:  t&31 = 16 s + 8 (j>>2) + 4 hh + (j&3)
+//    (see cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MMT_WAVE 64
+#define MMT_THREADS 256
+
+// D(16x16) += A(16x32) * B(32x16): lane l holds A[l&15][8(l>>4)+j], B[8(l>>4)+j][l&15];
+// D: col = l&15, row = 4(l>>4) + reg.
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// D(32x32) += A(32x16) * B(16x32): lane l (r=l&31, hh=l>>5) holds A[r][8hh+j], B[8hh+j][r];
+// D: col = r, row = (reg&3) + 8(reg>>2) + 4hh.
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// row index (0..31) of accumulator register `reg` of a 32x32 MFMA result for lane-half hh
+__device__ __forceinline__ int acc32_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+
+// pack 8 accumulator registers [8s .. 8s+7] into one bf16 operand fragment
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16)v[8 * s + j];
+    return r;
+}
+
+// ---- fragment layout index maps (element offsets inside one (batch,head) matrix) ----------------
+// R layout: tile-major, then 8-feature chunk, then window-in-tile, then feature-in-chunk.
+__device__ __forceinline__ size_t fragR_index(int t, int e, int DKP) {
+    return ((size_t)(t >> 5) * (DKP >> 3) + (e >> 3)) * 256 + (size_t)(t & 31) * 8 + (e & 7);
+}
+// T layout: 32 feature rows are always stored (rows >= DKP stay zero).
+__device__ __forceinline__ size_t fragT_index(int t, int e) {
+    const int s = (t >> 4) & 1, hh = (t >> 2) & 1, j = 4 * ((t >> 3) & 1) + (t & 3);
+    return ((((size_t)(t >> 5) * 2 + s) * 2 + hh) * 32 + e) * 8 + j;
+}
+__host__ __device__ __forceinline__ size_t fragR_elems(int Tp, int DKP) { return (size_t)Tp * DKP; }
+__host__ __device__ __forceinline__ size_t fragT_elems(int Tp) { return (size_t)Tp * 32; }
+
+__host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// counter-based hash RNG for dropout: one 32-bit word per (seed, stream, index)
+__device__ __forceinline__ uint32_t hash_u32(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx) {
+    uint32_t x = idx * 0x9E3779B1u + seed_lo;
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x += seed_hi; x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}

@@ -1,0 +1,339 @@
+// Support kernels around the row-local GEMM and the attention core:
+//   * encoder_prep_kernel  — fp32 master weights (flat, reference layout) -> zero-padded bf16 operand
+//                            copies (forward and transposed forms, head-padded where heads are < 16 wide)
+//   * layernorm_fwd/bwd    — the reference's LayerNorm alone (final norm of a stack; standalone module)
+//   * wgrad_kernel         — dW[n][k] = sum_m dY[m][n] X[m][k] from T-layout operands, split over windows
+//   * finalize kernels     — deterministic sums of the split slabs into the flat fp32 gradient
+#pragma once
+#include "common.h"
+
+// ---- flat parameter layout of one encoder layer (fp32 elements), mirroring the reference's
+//      registration order (transformer/MFT/multiTransformer.py:43,15-16,100,84-85)
+struct LayerLayout {
+    int d, f, h, dk, DKP, HD, HDP, DP, FP, NQ;
+    __host__ __device__ size_t oW(int i) const { return (size_t)i * ((size_t)d * d + d); }   // linears[i].weight
+    __host__ __device__ size_t ob(int i) const { return oW(i) + (size_t)d * d; }             // linears[i].bias
+    __host__ __device__ size_t oW1() const { return oW(4); }
+    __host__ __device__ size_t ob1() const { return oW1() + (size_t)f * d; }
+    __host__ __device__ size_t oW2() const { return ob1() + f; }
+    __host__ __device__ size_t ob2() const { return oW2() + (size_t)d * f; }
+    __host__ __device__ size_t oln(int i) const { return ob2() + d + (size_t)i * d; }        // ln1.a, ln1.b, ln2.a, ln2.b
+    __host__ __device__ size_t stride() const { return oln(4); }
+    // prepared (bf16) block of one layer
+    __host__ __device__ size_t pWqkv() const { return 0; }
+    __host__ __device__ size_t pWqkvT() const { return pWqkv() + (size_t)NQ * DP; }
+    __host__ __device__ size_t pWo() const { return pWqkvT() + (size_t)DP * NQ; }
+    __host__ __device__ size_t pWoT() const { return pWo() + (size_t)DP * HDP; }
+    __host__ __device__ size_t pW1() const { return pWoT() + (size_t)HDP * DP; }
+    __host__ __device__ size_t pW1T() const { return pW1() + (size_t)FP * DP; }
+    __host__ __device__ size_t pW2() const { return pW1T() + (size_t)DP * FP; }
+    __host__ __device__ size_t pW2T() const { return pW2() + (size_t)DP * FP; }
+    __host__ __device__ size_t pstride() const { return pW2T() + (size_t)FP * DP; }
+    // prepared (fp32) padded biases of one layer
+    __host__ __device__ size_t qbqkv() const { return 0; }
+    __host__ __device__ size_t qbo() const { return NQ; }
+    __host__ __device__ size_t qb1() const { return (size_t)NQ + DP; }
+    __host__ __device__ size_t qb2() const { return (size_t)NQ + DP + FP; }
+    __host__ __device__ size_t qstride() const { return (size_t)NQ + 2 * DP + FP; }
+};
+
+inline LayerLayout make_layout(int d, int f, int h) {
+    LayerLayout L;
+    L.d = d; L.f = f; L.h = h; L.dk = d / h;
+    L.DKP = (L.dk <= 16) ? 16 : 32;
+    L.HD = h * L.DKP; L.HDP = round_up(L.HD, 64);
+    L.DP = round_up(d, 64); L.FP = round_up(f, 64);
+    L.NQ = round_up(3 * L.HD, 64);
+    return L;
+}
+
+// source feature index of head-padded column c (= head*DKP + e), or -1 for a pad column
+__device__ __forceinline__ int unpad_head(int c, const LayerLayout& L) {
+    if (c >= L.HD) return -1;
+    const int head = c / L.DKP, e = c - head * L.DKP;
+    return (e < L.dk) ? head * L.dk + e : -1;
+}
+
+// grid = (blocks, n_layers); every element of the prepared block is computed from its coordinates
+__global__ void encoder_prep_kernel(const float* __restrict__ params, bf16* __restrict__ wprep,
+                                    float* __restrict__ bprep, LayerLayout L) {
+    const float* P = params + (size_t)blockIdx.y * L.stride();
+    bf16* W = wprep + (size_t)blockIdx.y * L.pstride();
+    float* Bp = bprep + (size_t)blockIdx.y * L.qstride();
+    const size_t total = L.pstride();
+    const int d = L.d, f = L.f;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total + L.qstride();
+         idx += (size_t)gridDim.x * blockDim.x) {
+        if (idx >= total) {                 // padded fp32 biases
+            const int i = (int)(idx - total);
+            float v = 0.f;
+            if (i < L.NQ) {
+                const int wi = i / L.HD;
+                if (wi < 3) { const int s = unpad_head(i - wi * L.HD, L); if (s >= 0) v = P[L.ob(wi) + s]; }
+            } else if (i < L.NQ + L.DP) { const int n = i - L.NQ; if (n < d) v = P[L.ob(3) + n]; }
+            else if (i < L.NQ + L.DP + L.FP) { const int n = i - L.NQ - L.DP; if (n < f) v = P[L.ob1() + n]; }
+            else { const int n = i - L.NQ - L.DP - L.FP; if (n < d) v = P[L.ob2() + n]; }
+            Bp[i] = v;
+            continue;
+        }
+        float v = 0.f;
+        if (idx < L.pWqkvT()) {             // Wqkv [NQ][DP]: row = (wi*h+head)*DKP+e, col = input feature
+            const int n = (int)(idx / L.DP), k = (int)(idx % L.DP), wi = n / L.HD;
+            if (wi < 3 && k < d) { const int s = unpad_head(n - wi * L.HD, L); if (s >= 0) v = P[L.oW(wi) + (size_t)s * d + k]; }
+        } else if (idx < L.pWo()) {         // Wqkv^T [DP][NQ]
+            const size_t i = idx - L.pWqkvT();
+            const int k = (int)(i / L.NQ), n = (int)(i % L.NQ), wi = n / L.HD;
+            if (wi < 3 && k < d) { const int s = unpad_head(n - wi * L.HD, L); if (s >= 0) v = P[L.oW(wi) + (size_t)s * d + k]; }
+        } else if (idx < L.pWoT()) {        // Wo [DP][HDP]: col = head-padded context feature
+            const size_t i = idx - L.pWo();
+            const int n = (int)(i / L.HDP), c = (int)(i % L.HDP);
+            if (n < d) { const int s = unpad_head(c, L); if (s >= 0) v = P[L.oW(3) + (size_t)n * d + s]; }
+        } else if (idx < L.pW1()) {         // Wo^T [HDP][DP]
+            const size_t i = idx - L.pWoT();
+            const int c = (int)(i / L.DP), n = (int)(i % L.DP);
+            if (n < d) { const int s = unpad_head(c, L); if (s >= 0) v = P[L.oW(3) + (size_t)n * d + s]; }
+        } else if (idx < L.pW1T()) {        // W1 [FP][DP]
+            const size_t i = idx - L.pW1();
+            const int n = (int)(i / L.DP), k = (int)(i % L.DP);
+            if (n < f && k < d) v = P[L.oW1() + (size_t)n * d + k];
+        } else if (idx < L.pW2()) {         // W1^T [DP][FP]
+            const size_t i = idx - L.pW1T();
+            const int k = (int)(i / L.FP), n = (int)(i % L.FP);
+            if (n < f && k < d) v = P[L.oW1() + (size_t)n * d + k];
+        } else if (idx < L.pW2T()) {        // W2 [DP][FP]
+            const size_t i = idx - L.pW2();
+            const int n = (int)(i / L.FP), k = (int)(i % L.FP);
+            if (n < d && k < f) v = P[L.oW2() + (size_t)n * f + k];
+        } else {                            // W2^T [FP][DP]
+            const size_t i = idx - L.pW2T();
+            const int k = (int)(i / L.DP), n = (int)(i % L.DP);
+            if (n < d && k < f) v = P[L.oW2() + (size_t)n * f + k];
+        }
+        W[idx] = (bf16)v;
+    }
+}
+
+// generic: fp32 [N][K] (ld = K) -> bf16 [NP][KP] zero padded, optionally transposed source
+__global__ void pad_cast_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int N, int K, int NP, int KP,
+                                int transpose_src) {
+    const size_t total = (size_t)NP * KP;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / KP), k = (int)(idx % KP);
+        float v = 0.f;
+        if (n < N && k < K) v = transpose_src ? src[(size_t)k * N + n] : src[(size_t)n * K + k];
+        dst[idx] = (bf16)v;
+    }
+}
+
+// ---- LayerNorm alone (reference variant).  8 threads per row, 32 rows per workgroup. -------------
+__global__ __launch_bounds__(MMT_THREADS) void layernorm_fwd_kernel(
+        const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b, float eps,
+        float* __restrict__ y, float* __restrict__ stats, int M, int d) {
+    const int row = threadIdx.x >> 3, j = threadIdx.x & 7, m = blockIdx.x * 32 + row;
+    const bool ok = m < M;
+    const float* xr = x + (size_t)(ok ? m : 0) * d;
+    float s = 0.f;
+    for (int c = j * 4; c < d; c += 32) { f32x4 v = *reinterpret_cast<const f32x4*>(xr + c); s += (v[0] + v[1]) + (v[2] + v[3]); }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    const float mean = s / (float)d;
+    float q = 0.f;
+    for (int c = j * 4; c < d; c += 32) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float t = v[i] - mean; q += t * t; }
+    }
+    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+    const float rstd = 1.0f / (sqrtf(q / (float)(d - 1)) + eps);
+    if (!ok) return;
+    if (j == 0 && stats) { stats[2 * (size_t)m] = mean; stats[2 * (size_t)m + 1] = rstd; }
+    for (int c = j * 4; c < d; c += 32) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        f32x4 av = *reinterpret_cast<const f32x4*>(a + c), bv = *reinterpret_cast<const f32x4*>(b + c), o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = av[i] * ((v[i] - mean) * rstd) + bv[i];
+        *reinterpret_cast<f32x4*>(y + (size_t)m * d + c) = o;
+    }
+}
+
+// dx = LNbwd(dy); per-workgroup column sums for d ln_b (sum dy) and d ln_a (sum dy*xhat) -> colpart[g][2][DP]
+__global__ __launch_bounds__(MMT_THREADS) void layernorm_bwd_kernel(
+        const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ a,
+        const float* __restrict__ stats, float eps, float* __restrict__ dx, float* __restrict__ colpart,
+        int M, int d, int DP) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Fs = reinterpret_cast<float*>(smem);            // [32][DP+4]  dy
+    float* Gs = Fs + 32 * (DP + 4);                        // [32][DP+4]  dy * xhat
+    const int ld = DP + 4;
+    const int row = threadIdx.x >> 3, j = threadIdx.x & 7, m = blockIdx.x * 32 + row;
+    const bool ok = m < M;
+    float mean = 0.f, rstd = 1.f;
+    if (ok) { mean = stats[2 * (size_t)m]; rstd = stats[2 * (size_t)m + 1]; }
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = j * 4; c < DP; c += 32) {
+        f32x4 g = {0.f, 0.f, 0.f, 0.f}, gx = g;
+        if (ok && c < d) {
+            g = *reinterpret_cast<const f32x4*>(dy + (size_t)m * d + c);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)m * d + c);
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float xh = (xv[i] - mean) * rstd;
+                gx[i] = g[i] * xh;
+                s1 += g[i] * av[i];
+                s2 += g[i] * av[i] * xh;
+            }
+        }
+        *reinterpret_cast<f32x4*>(Fs + row * ld + c) = g;
+        *reinterpret_cast<f32x4*>(Gs + row * ld + c) = gx;
+    }
+    s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+    s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
+    if (ok) {
+        const float sigma = 1.0f / rstd - eps;
+        const float k1 = s1 / (float)d, k2 = s2 / ((float)(d - 1) * sigma);
+        for (int c = j * 4; c < d; c += 32) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(Fs + row * ld + c);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)m * d + c);
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a + c);
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = rstd * (g[i] * av[i] - k1) - k2 * ((xv[i] - mean) * rstd);
+            *reinterpret_cast<f32x4*>(dx + (size_t)m * d + c) = o;
+        }
+    }
+    __syncthreads();
+    if (colpart) {
+        for (int c = threadIdx.x; c < DP; c += MMT_THREADS) {
+            float sb = 0.f, sa = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) { sb += Fs[r * ld + c]; sa += Gs[r * ld + c]; }
+            colpart[(size_t)blockIdx.x * 2 * DP + c] = sb;
+            colpart[(size_t)blockIdx.x * 2 * DP + DP + c] = sa;
+        }
+    }
+}
+
+// ---- weight gradients ---------------------------------------------------------------------------
+// dW[n][k] = sum_m At[n][m] * Bt[k][m]  (At = dY^T, Bt = X^T, both T layout [rows][MP], bf16).
+// One workgroup = one 64x64 output tile (4 waves as 2x2 of 32x32) over one slice of the windows;
+// slices go to separate fp32 slabs [nsplit][NP][KP] (+ [nsplit][NP] for the bias gradient = row sums
+// of At, taken from the A fragments on VALU), summed later by wgrad_finalize (deterministic).
+struct WgradJob {
+    const bf16* At; const bf16* Bt; float* out; float* bias_out;
+    int NPj, KPj, tile0, tiles_k;
+};
+#define MMT_MAX_WGRAD_JOBS 8
+struct WgradJobs { WgradJob j[MMT_MAX_WGRAD_JOBS]; int njobs; int MP; int M16; int mchunk; };
+
+__global__ __launch_bounds__(MMT_THREADS) void wgrad_kernel(const WgradJobs jobs) {
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < MMT_MAX_WGRAD_JOBS; ++i) if (i < jobs.njobs && (int)blockIdx.x >= jobs.j[i].tile0) ji = i;
+    const WgradJob J = jobs.j[ji];
+    const int tile = blockIdx.x - J.tile0, tn = tile / J.tiles_k, tk = tile - tn * J.tiles_k;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const int n0 = tn * 64 + (wave >> 1) * 32, k0 = tk * 64 + (wave & 1) * 32;
+    const int split = blockIdx.y;
+    const int mbeg = split * jobs.mchunk, mend = min(jobs.M16, mbeg + jobs.mchunk);
+    const bf16* ap = J.At + (size_t)(n0 + r) * jobs.MP + 8 * hh;
+    const bf16* bp = J.Bt + (size_t)(k0 + r) * jobs.MP + 8 * hh;
+    const bool want_bias = (J.bias_out != nullptr) && tk == 0 && (wave & 1) == 0;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float bsum = 0.f;
+    int m = mbeg;
+    for (; m + 64 <= mend; m += 64) {
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const bf16x8*>(ap + m + 16 * u);
+            b[u] = *reinterpret_cast<const bf16x8*>(bp + m + 16 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = mfma32(a[u], b[u], acc);
+            if (want_bias) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bsum += (float)a[u][i];
+            }
+        }
+    }
+    for (; m < mend; m += 16) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + m);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp + m);
+        acc = mfma32(a, b, acc);
+        if (want_bias) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bsum += (float)a[i];
+        }
+    }
+    float* out = J.out + (size_t)split * J.NPj * J.KPj;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[(size_t)(n0 + acc32_row(i, hh)) * J.KPj + k0 + r] = acc[i];
+    if (want_bias) {
+        bsum += __shfl_xor(bsum, 32);
+        if (hh == 0) J.bias_out[(size_t)split * J.NPj + n0 + r] = bsum;
+    }
+}
+
+// generic slab sum with crop: dst[n][k] (ld = K) = sum_s slab[s][n][k] for n<N, k<K
+__global__ void slab_sum_kernel(const float* __restrict__ slab, int nsplit, int NP, int KP,
+                                float* __restrict__ dst, int N, int K) {
+    const size_t total = (size_t)N * K;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / K), k = (int)(idx % K);
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += slab[((size_t)sp * NP + n) * KP + k];
+        dst[idx] = s;
+    }
+}
+
+// Encoder layer gradients -> flat fp32 gradient block of the layer (same layout as the parameters).
+struct LayerSlabs {
+    const float *dWqkv, *dbqkv, *dWo, *dbo, *dW1, *db1, *dW2, *db2;   // [nsplit][..]
+    const float *ln1part, *ln2part;                                    // [G][2][DP]
+    int nsplit, G;
+};
+
+__global__ void encoder_finalize_kernel(LayerSlabs S, LayerLayout L, float* __restrict__ grad) {
+    const int d = L.d, f = L.f;
+    const size_t n_w = L.oln(0);                   // weights and biases of the layer
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_w; idx += (size_t)gridDim.x * blockDim.x) {
+        const float* src; size_t off, sstride;
+        if (idx < L.oW1()) {                        // the four attention linears
+            const int wi = (int)(idx / ((size_t)d * d + d));
+            const size_t r = idx - L.oW(wi);
+            if (r < (size_t)d * d) {
+                const int n = (int)(r / d), k = (int)(r % d);
+                if (wi < 3) {                       // row n = head*dk+e -> head-padded row of dWqkv
+                    const int head = n / L.dk, e = n - head * L.dk;
+                    src = S.dWqkv; off = ((size_t)wi * L.HD + head * L.DKP + e) * L.DP + k; sstride = (size_t)L.NQ * L.DP;
+                } else {                            // Wo column k = head*dk+e -> head-padded column
+                    const int head = k / L.dk, e = k - head * L.dk;
+                    src = S.dWo; off = (size_t)n * L.HDP + head * L.DKP + e; sstride = (size_t)L.DP * L.HDP;
+                }
+            } else {
+                const int n = (int)(r - (size_t)d * d);
+                if (wi < 3) { const int head = n / L.dk, e = n - head * L.dk; src = S.dbqkv; off = (size_t)wi * L.HD + head * L.DKP + e; sstride = L.NQ; }
+                else { src = S.dbo; off = n; sstride = L.DP; }
+            }
+        } else if (idx < L.ob1()) { const size_t r = idx - L.oW1(); src = S.dW1; off = (r / d) * L.DP + (r % d); sstride = (size_t)L.FP * L.DP; }
+        else if (idx < L.oW2()) { src = S.db1; off = idx - L.ob1(); sstride = L.FP; }
+        else if (idx < L.ob2()) { const size_t r = idx - L.oW2(); src = S.dW2; off = (r / f) * L.FP + (r % f); sstride = (size_t)L.DP * L.FP; }
+        else { src = S.db2; off = idx - L.ob2(); sstride = L.DP; }
+        float s = 0.f;
+        for (int sp = 0; sp < S.nsplit; ++sp) s += src[(size_t)sp * sstride + off];
+        grad[idx] = s;
+    }
+}
+
+// LayerNorm parameter gradients: out_a[c] = sum_g part[g][1][c], out_b[c] = sum_g part[g][0][c]
+__global__ void ln_param_finalize_kernel(const float* __restrict__ part, int G, int DP, int d,
+                                         float* __restrict__ out_a, float* __restrict__ out_b) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    float sa = 0.f, sb = 0.f;
+    for (int g = 0; g < G; ++g) { sb += part[(size_t)g * 2 * DP + c]; sa += part[(size_t)g * 2 * DP + DP + c]; }
+    out_a[c] = sa; out_b[c] = sb;
+}

@@ -1,0 +1,372 @@
+// Row-local GEMM for gfx950:  C[M][N] = epilogue( prologue(A)[M][K] . W[N][K]^T ).
+//
+// Every window-local step of the encoder (QKV projection, output projection, the two FFN
+// products, their backward input-gradients, embeds, read-out MLPs) is an instance of this kernel.
+// One workgroup (4 waves) owns 32 consecutive windows:
+//   1. A tile -> LDS as bf16 [32][KP+8] (optionally through the reference's LayerNorm, computed
+//      in fp32 from an fp32 LDS staging copy; optionally emitting the feature-major "T layout"
+//      copy that the weight-gradient kernel contracts over windows);
+//   2. per 128-column chunk, wave w multiplies the tile by W rows [n0+32w, n0+32w+32) with
+//      mfma_f32_16x16x32_bf16 (W fragments straight from L2: each is used by exactly one wave,
+//      two k-blocks in flight), and parks its fp32 accumulators in an LDS tile;
+//   3. a row-wise epilogue reads that LDS tile with a thread->(row, 4 columns) mapping, so all
+//      global traffic is 8/16-byte coalesced whatever the MFMA accumulator layout was.
+// Epilogues: PLAIN (bias/ReLU/ReLU-mask/residual/row-scale; fp32, bf16 and T-layout outputs),
+//            FRAG  (attention operand fragment layouts for Q/K/V or dO, plus delta = rowsum(dO.O)),
+//            LNBWD (LayerNorm backward fused behind the input-gradient GEMM + residual gradient).
+#pragma once
+#include "common.h"
+
+enum { EPI_PLAIN = 0, EPI_FRAG = 1, EPI_LNBWD = 2 };
+
+struct RowGemmParams {
+    int M, K, KP, N, NP;
+    // ---- A operand ----
+    const void* A; int a_bf16; int lda;
+    bf16* At_out; int ldt;                 // optional T-layout copy of the bf16 A tile: [KP][ldt]
+    // LayerNorm prologue (A must be fp32, K = feature count)
+    const float* ln_a; const float* ln_b; float eps; float* stats;   // stats: [M][2] = (mean, 1/(std+eps))
+    // ---- W operand: bf16 [NP][KP], zero padded; bias fp32 [NP] zero padded ----
+    const bf16* W; const float* bias;
+    // ---- PLAIN ----
+    int act;                               // 1 = ReLU
+    const bf16* relu_mask; int ldm;        // multiply by (relu_mask[m][n] > 0)
+    const float* residual; int ldr;
+    const float* rowscale;                 // multiply row m by rowscale[m]
+    float* out_f32; int ldo;
+    bf16* out_bf16; int ldo16; int n_store16;   // columns [0, n_store16) are written (pads come out as exact zeros)
+    bf16* out_T; int ldoT;                 // [NP][ldoT]
+    // ---- FRAG ----
+    bf16* fragR[3]; bf16* fragT[3];
+    int T, Tp, h, DKP, nwhich;             // N covers nwhich * h * DKP columns
+    const float* rowmask; float qscale; int scale_first;   // first matrix: *qscale and zero where rowmask==0
+    const bf16* ctx; int ldctx; float* delta;              // delta[bh][Tp] = sum_e C*ctx (dO epilogue)
+    // ---- LNBWD ----
+    const float* x; int ldx; const float* st; const float* dres; int lddres;
+    float* colpart;                        // [gridDim.x][2][NP]: per-workgroup column sums (d ln_b, d ln_a)
+    int d_real;
+};
+
+__host__ __device__ inline int rowgemm_fw(int EPI, bool lnpro, int KP, int NP) {
+    int cw = (EPI == EPI_LNBWD) ? NP : 128;
+    int fw = cw;
+    if (lnpro && KP > fw) fw = KP;
+    return fw;
+}
+inline size_t rowgemm_lds_bytes(int EPI, bool lnpro, int KP, int NP) {
+    size_t a = (size_t)32 * (KP + 8) * 2;
+    size_t f = (size_t)32 * (rowgemm_fw(EPI, lnpro, KP, NP) + 4) * 4;
+    size_t g = (EPI == EPI_LNBWD) ? (size_t)32 * (NP + 4) * 4 : 0;
+    return a + f + g;
+}
+
+template <int EPI, bool LNPRO>
+__global__ __launch_bounds__(MMT_THREADS) void rowgemm_kernel(const RowGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KP = p.KP, NP = p.NP, K = p.K, M = p.M;
+    const int lda_s = KP + 8;                                  // A tile row stride (bf16 elements)
+    const int FW = rowgemm_fw(EPI, LNPRO, KP, NP), ldf = FW + 4;
+    bf16* As = reinterpret_cast<bf16*>(smem);
+    float* Fs = reinterpret_cast<float*>(smem + (size_t)32 * lda_s * 2);
+    float* Gs = Fs + (size_t)32 * ldf;                          // LNBWD only
+    const int m0 = blockIdx.x * 32;
+
+    // ------------------------------------------------------------------ 1. A tile -> LDS (bf16)
+    if (LNPRO) {
+        const float* A = static_cast<const float*>(p.A);
+        const int k4 = KP >> 2;
+        for (int idx = tid; idx < 32 * k4; idx += MMT_THREADS) {
+            const int row = idx / k4, c = (idx - row * k4) * 4, m = m0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < M && c < K) v = *reinterpret_cast<const f32x4*>(A + (size_t)m * p.lda + c);
+            *reinterpret_cast<f32x4*>(Fs + row * ldf + c) = v;
+        }
+        __syncthreads();
+        // 8 threads per row; LayerNorm of the reference: unbiased std, eps added to std
+        const int row = tid >> 3, j = tid & 7, m = m0 + row;
+        const float* xr = Fs + row * ldf;
+        float s = 0.f;
+        for (int c = j * 4; c < K; c += 32) { f32x4 v = *reinterpret_cast<const f32x4*>(xr + c); s += (v[0] + v[1]) + (v[2] + v[3]); }
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        const float mean = s / (float)K;
+        float q = 0.f;
+        for (int c = j * 4; c < K; c += 32) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { float dlt = v[i] - mean; q += dlt * dlt; }
+        }
+        q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+        const float sigma = sqrtf(q / (float)(K - 1));
+        const float rstd = 1.0f / (sigma + p.eps);
+        if (j == 0 && m < M && p.stats) { p.stats[2 * (size_t)m] = mean; p.stats[2 * (size_t)m + 1] = rstd; }
+        for (int c = j * 4; c < KP; c += 32) {
+            bf16x4 o = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+            if (c < K && m < M) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+                f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_a + c);
+                f32x4 b = *reinterpret_cast<const f32x4*>(p.ln_b + c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (bf16)(a[i] * ((v[i] - mean) * rstd) + b[i]);
+            }
+            *reinterpret_cast<bf16x4*>(As + row * lda_s + c) = o;
+        }
+    } else if (p.a_bf16) {
+        const bf16* A = static_cast<const bf16*>(p.A);
+        const int k8 = KP >> 3;
+        for (int idx = tid; idx < 32 * k8; idx += MMT_THREADS) {
+            const int row = idx / k8, c = (idx - row * k8) * 8, m = m0 + row;
+            bf16x8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (bf16)0.f;
+            if (m < M && c < K) v = *reinterpret_cast<const bf16x8*>(A + (size_t)m * p.lda + c);
+            *reinterpret_cast<bf16x8*>(As + row * lda_s + c) = v;
+        }
+    } else {
+        const float* A = static_cast<const float*>(p.A);
+        const int k4 = KP >> 2;
+        for (int idx = tid; idx < 32 * k4; idx += MMT_THREADS) {
+            const int row = idx / k4, c = (idx - row * k4) * 4, m = m0 + row;
+            bf16x4 o = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+            if (m < M && c < K) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(A + (size_t)m * p.lda + c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (bf16)v[i];
+            }
+            *reinterpret_cast<bf16x4*>(As + row * lda_s + c) = o;
+        }
+    }
+    __syncthreads();
+
+    if (p.At_out) {   // T-layout copy of the bf16 tile: task = (feature k, group of 8 rows)
+        for (int task = tid; task < KP * 4; task += MMT_THREADS) {
+            const int k = task % KP, rg = task / KP, mb = m0 + rg * 8;
+            if (mb >= M) continue;
+            bf16x8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = As[(rg * 8 + i) * lda_s + k];
+            bf16* dst = p.At_out + (size_t)k * p.ldt + mb;
+            if (mb + 8 <= M) *reinterpret_cast<bf16x8*>(dst) = v;
+            else for (int i = 0; i < 8 && mb + i < M; ++i) dst[i] = v[i];
+        }
+    }
+
+    // ------------------------------------------------------------------ 2. chunks of 128 columns
+    const int l15 = lane & 15, lq = lane >> 4;
+    for (int n0 = 0; n0 < NP; n0 += 128) {
+        const int nb = n0 + wave * 32;
+        if (nb < NP) {
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bf16* wrow0 = p.W + (size_t)(nb + l15) * KP + 8 * lq;
+            const bf16* wrow1 = wrow0 + (size_t)16 * KP;
+            const bf16* arow0 = As + l15 * lda_s + 8 * lq;
+            const bf16* arow1 = arow0 + 16 * lda_s;
+            bf16x8 b00 = *reinterpret_cast<const bf16x8*>(wrow0);
+            bf16x8 b01 = *reinterpret_cast<const bf16x8*>(wrow1);
+            bf16x8 b10 = *reinterpret_cast<const bf16x8*>(wrow0 + 32);
+            bf16x8 b11 = *reinterpret_cast<const bf16x8*>(wrow1 + 32);
+            for (int kb = 0; kb < KP; kb += 64) {
+                bf16x8 n00 = b00, n01 = b01, n10 = b10, n11 = b11;
+                if (kb + 64 < KP) {          // next k-block's W fragments in flight behind this block's MFMAs
+                    n00 = *reinterpret_cast<const bf16x8*>(wrow0 + kb + 64);
+                    n01 = *reinterpret_cast<const bf16x8*>(wrow1 + kb + 64);
+                    n10 = *reinterpret_cast<const bf16x8*>(wrow0 + kb + 96);
+                    n11 = *reinterpret_cast<const bf16x8*>(wrow1 + kb + 96);
+                }
+                const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(arow0 + kb);
+                const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(arow1 + kb);
+                const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(arow0 + kb + 32);
+                const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(arow1 + kb + 32);
+                acc[0][0] = mfma16(a00, b00, acc[0][0]);
+                acc[0][1] = mfma16(a00, b01, acc[0][1]);
+                acc[1][0] = mfma16(a01, b00, acc[1][0]);
+                acc[1][1] = mfma16(a01, b01, acc[1][1]);
+                acc[0][0] = mfma16(a10, b10, acc[0][0]);
+                acc[0][1] = mfma16(a10, b11, acc[0][1]);
+                acc[1][0] = mfma16(a11, b10, acc[1][0]);
+                acc[1][1] = mfma16(a11, b11, acc[1][1]);
+                b00 = n00; b01 = n01; b10 = n10; b11 = n11;
+            }
+            const int cbase = ((EPI == EPI_LNBWD) ? nb : wave * 32) + l15;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Fs[(mt * 16 + 4 * lq + r) * ldf + cbase + nt * 16] = acc[mt][nt][r];
+        }
+        if (EPI == EPI_LNBWD) continue;
+        __syncthreads();
+
+        // -------------------------------------------------------------- 3. row-wise epilogue (chunk)
+        if (EPI == EPI_PLAIN) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int task = tid + it * MMT_THREADS;
+                const int row = task >> 5, cg = task & 31, n = n0 + cg * 4, m = m0 + row;
+                if (n >= NP) continue;
+                f32x4 v = *reinterpret_cast<const f32x4*>(Fs + row * ldf + cg * 4);
+                if (m < M) {
+                    if (p.bias) { f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n); v += b; }
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                    }
+                    if (p.relu_mask) {
+                        bf16x4 mk = *reinterpret_cast<const bf16x4*>(p.relu_mask + (size_t)m * p.ldm + n);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = ((float)mk[i] > 0.f) ? v[i] : 0.f;
+                    }
+                    if (p.residual) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) if (n + i < p.N) v[i] += p.residual[(size_t)m * p.ldr + n + i];
+                    }
+                    if (p.rowscale) { const float rs = p.rowscale[m]; v *= rs; }
+                    if (p.out_f32) {
+                        float* dst = p.out_f32 + (size_t)m * p.ldo + n;
+                        if (n + 4 <= p.N && (p.ldo & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+                        else for (int i = 0; i < 4 && n + i < p.N; ++i) dst[i] = v[i];
+                    }
+                    if (p.out_bf16 && n < p.n_store16) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = (bf16)v[i];
+                        bf16* dst = p.out_bf16 + (size_t)m * p.ldo16 + n;
+                        if (n + 4 <= p.n_store16 && (p.ldo16 & 3) == 0) *reinterpret_cast<bf16x4*>(dst) = o;
+                        else for (int i = 0; i < 4 && n + i < p.n_store16; ++i) dst[i] = o[i];
+                    }
+                } else {
+                    v = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if (p.out_T) *reinterpret_cast<f32x4*>(Fs + row * ldf + cg * 4) = v;   // final values for the T pass
+            }
+            if (p.out_T) {
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int task = tid + it * MMT_THREADS;
+                    const int c = task & 127, rg = task >> 7, n = n0 + c, mb = m0 + rg * 8;
+                    if (n >= NP || mb >= M) continue;
+                    bf16x8 v;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (bf16)Fs[(rg * 8 + i) * ldf + c];
+                    bf16* dst = p.out_T + (size_t)n * p.ldoT + mb;
+                    if (mb + 8 <= M) *reinterpret_cast<bf16x8*>(dst) = v;
+                    else for (int i = 0; i < 8 && mb + i < M; ++i) dst[i] = v[i];
+                }
+            }
+        } else if (EPI == EPI_FRAG) {
+            const int HD = p.h * p.DKP;
+            const size_t szR = fragR_elems(p.Tp, p.DKP), szT = fragT_elems(p.Tp);
+            const int nred = p.DKP >> 2;                 // lanes per head (4 or 8), aligned groups
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int task = tid + it * MMT_THREADS;
+                const int row = task >> 5, cg = task & 31, n = n0 + cg * 4, m = m0 + row;
+                const bool ok = (m < M) && (n < p.nwhich * HD);
+                float part = 0.f;
+                int bh = 0, t = 0, e = 0;
+                if (ok) {
+                    const int wi = n / HD, rem = n - wi * HD, head = rem / p.DKP;
+                    e = rem - head * p.DKP;
+                    const int b = m / p.T;
+                    t = m - b * p.T;
+                    bh = b * p.h + head;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(Fs + row * ldf + cg * 4);
+                    if (p.bias) { f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + n); v += bb; }
+                    if (p.scale_first && wi == 0) {
+                        const float sc = (p.rowmask[m] == 0.0f) ? 0.f : p.qscale;   // mask == 0 -> blank query row
+                        v *= sc;
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (bf16)v[i];
+                    *reinterpret_cast<bf16x4*>(p.fragR[wi] + bh * szR + fragR_index(t, e, p.DKP)) = o;
+                    bf16* dT = p.fragT[wi] + bh * szT;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dT[fragT_index(t, e + i)] = o[i];
+                    if (p.delta) {
+                        bf16x4 c4 = *reinterpret_cast<const bf16x4*>(p.ctx + (size_t)m * p.ldctx + rem);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) part += (float)o[i] * (float)c4[i];
+                    }
+                }
+                if (p.delta) {
+                    part += __shfl_xor(part, 1); part += __shfl_xor(part, 2);
+                    if (nred == 8) part += __shfl_xor(part, 4);
+                    if (ok && e == 0) p.delta[(size_t)bh * p.Tp + t] = part;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ LayerNorm backward epilogue
+    if (EPI == EPI_LNBWD) {
+        __syncthreads();
+        const int d = p.d_real;
+        const int row = tid >> 3, j = tid & 7, m = m0 + row;
+        float* cr = Fs + row * ldf;          // dxn = grad wrt LayerNorm output (fp32)
+        float* gr = Gs + row * (NP + 4);
+        float mean = 0.f, rstd = 0.f;
+        if (m < M) { mean = p.st[2 * (size_t)m]; rstd = p.st[2 * (size_t)m + 1]; }
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = j * 4; c < NP; c += 32) {
+            f32x4 g = {0.f, 0.f, 0.f, 0.f}, xh = {0.f, 0.f, 0.f, 0.f};
+            if (m < M && c < d) {
+                f32x4 dy = *reinterpret_cast<const f32x4*>(cr + c);
+                f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + c);
+                f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_a + c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xh[i] = (xv[i] - mean) * rstd;
+                    g[i] = dy[i] * a[i];
+                    s1 += g[i];
+                    s2 += g[i] * xh[i];
+                }
+                // column-sum operands: Fs keeps dy (-> d ln_b), Gs gets dy * xhat (-> d ln_a)
+                f32x4 gx;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gx[i] = dy[i] * xh[i];
+                *reinterpret_cast<f32x4*>(gr + c) = gx;
+            } else {
+                *reinterpret_cast<f32x4*>(cr + c) = g;
+                *reinterpret_cast<f32x4*>(gr + c) = g;
+            }
+        }
+        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+        s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
+        if (m < M) {
+            const float sigma = 1.0f / rstd - p.eps;
+            const float k1 = s1 / (float)d, k2 = s2 / ((float)(d - 1) * sigma);
+            for (int c = j * 4; c < d; c += 32) {
+                f32x4 dy = *reinterpret_cast<const f32x4*>(cr + c);
+                f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + c);
+                f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_a + c);
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float xh = (xv[i] - mean) * rstd;
+                    o[i] = rstd * (dy[i] * a[i] - k1) - k2 * xh;
+                }
+                if (p.dres) { f32x4 r = *reinterpret_cast<const f32x4*>(p.dres + (size_t)m * p.lddres + c); o += r; }
+                *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + c) = o;
+            }
+        }
+        __syncthreads();
+        if (p.colpart) {
+            for (int c = tid; c < NP; c += MMT_THREADS) {
+                float sb = 0.f, sa = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < 32; ++r) { sb += Fs[r * ldf + c]; sa += Gs[r * (NP + 4) + c]; }
+                float* dst = p.colpart + (size_t)blockIdx.x * 2 * NP;
+                dst[c] = sb; dst[NP + c] = sa;
+            }
+        }
+    }
+}

@@ -1,0 +1,188 @@
+"""torch.autograd bindings of the HIP entry points (include/mmt_hip.h).
+
+Each Function is the forward/backward pair of one reference class:
+  encoder_stack  <- Encoder.forward                  transformer/MFT/multiTransformer.py:73-76
+  layer_norm     <- LayerNorm.forward                :88-91
+  sdpa           <- attention()                      :22-34
+  linear         <- nn.Linear (+ReLU) call sites     :15-20,43,55,65
+All tensors must live on a HIP device; there is no CPU path.
+"""
+import torch
+
+from . import _lib
+
+
+def _f32c(t):
+    return t.detach().contiguous().float() if t is not None else None
+
+
+class _EncoderStackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask, flat_params, h, d_ff, n_layers, eps, dropout_p, seed):
+        lib = _lib.load()
+        _lib.require_hip(x, mask, flat_params)
+        x_, m_, p_ = _f32c(x), _f32c(mask), _f32c(flat_params)
+        B, T, d = x_.shape
+        if m_.numel() != B * T:
+            raise ValueError("mask must have B*T = %d elements (shape (B,T,1)), got %s" % (B * T, tuple(mask.shape)))
+        need = lib.mmt_encoder_param_count(d, d_ff, n_layers)
+        if p_.numel() != need:
+            raise ValueError("flat parameter buffer has %d elements, expected %d" % (p_.numel(), need))
+        nbytes = lib.mmt_encoder_workspace_bytes(B, T, d, h, d_ff, n_layers)
+        if nbytes == 0:
+            _lib.check(lib.mmt_encoder_forward(None, None, None, None, None, 0, B, T, d, h, d_ff, n_layers, eps, 0.0, 0, None))
+        ws = _lib.POOL.get(nbytes, x_.device)
+        y = torch.empty_like(x_)
+        _lib.check(lib.mmt_encoder_forward(_lib.ptr(x_), _lib.ptr(m_), _lib.ptr(p_), _lib.ptr(y), _lib.ptr(ws), nbytes,
+                                           B, T, d, h, d_ff, n_layers, eps, dropout_p, seed, _lib.stream_ptr()))
+        needs_bwd = any(ctx.needs_input_grad)
+        if needs_bwd:
+            ctx.save_for_backward(x_, m_, p_)
+            ctx.ws = ws
+            ctx.cfg = (B, T, d, h, d_ff, n_layers, eps, dropout_p, seed, nbytes)
+        else:
+            _lib.POOL.put(ws)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x_, m_, p_ = ctx.saved_tensors
+        B, T, d, h, d_ff, n_layers, eps, dropout_p, seed, nbytes = ctx.cfg
+        if ctx.ws is None:
+            raise RuntimeError("encoder_stack: backward called twice on the same forward (workspace already released)")
+        dy_ = _f32c(dy)
+        dx = torch.empty_like(x_)
+        dp = torch.empty_like(p_)           # fresh buffer per call: returned gradient views never alias later calls
+        _lib.check(lib.mmt_encoder_backward(_lib.ptr(dy_), _lib.ptr(x_), _lib.ptr(m_), _lib.ptr(p_), _lib.ptr(dx), _lib.ptr(dp),
+                                            _lib.ptr(ctx.ws), nbytes, B, T, d, h, d_ff, n_layers, eps, dropout_p, seed,
+                                            _lib.stream_ptr()))
+        _lib.POOL.put(ctx.ws)
+        ctx.ws = None
+        return dx, None, dp, None, None, None, None, None, None
+
+
+def encoder_stack(x, mask, flat_params, h, d_ff, n_layers, eps=1e-6, dropout_p=0.0, seed=0):
+    return _EncoderStackFn.apply(x, mask, flat_params, int(h), int(d_ff), int(n_layers), float(eps), float(dropout_p), int(seed))
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a_2, b_2, eps):
+        lib = _lib.load()
+        _lib.require_hip(x, a_2, b_2)
+        x_, a_, b_ = _f32c(x), _f32c(a_2), _f32c(b_2)
+        d = x_.shape[-1]
+        M = x_.numel() // d
+        y = torch.empty_like(x_)
+        stats = torch.empty(M, 2, dtype=torch.float32, device=x_.device)
+        _lib.check(lib.mmt_layernorm_forward(_lib.ptr(x_), _lib.ptr(a_), _lib.ptr(b_), _lib.ptr(y), _lib.ptr(stats), M, d, eps,
+                                             _lib.stream_ptr()))
+        ctx.save_for_backward(x_, a_, stats)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x_, a_, stats = ctx.saved_tensors
+        d = x_.shape[-1]
+        M = x_.numel() // d
+        dy_ = _f32c(dy)
+        dx = torch.empty_like(x_)
+        da = torch.empty_like(a_)
+        db = torch.empty_like(a_)
+        scratch = torch.empty(lib.mmt_layernorm_scratch_floats(M, d), dtype=torch.float32, device=x_.device)
+        _lib.check(lib.mmt_layernorm_backward(_lib.ptr(dy_), _lib.ptr(x_), _lib.ptr(a_), _lib.ptr(stats), _lib.ptr(dx),
+                                              _lib.ptr(da), _lib.ptr(db), _lib.ptr(scratch), M, d, ctx.eps, _lib.stream_ptr()))
+        return dx, da, db, None
+
+
+def layer_norm(x, a_2, b_2, eps=1e-6):
+    return _LayerNormFn.apply(x, a_2, b_2, float(eps))
+
+
+class _SdpaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, h):
+        lib = _lib.load()
+        _lib.require_hip(q, k, v, mask)
+        q_, k_, v_, m_ = _f32c(q), _f32c(k), _f32c(v), _f32c(mask)
+        B, T, d = q_.shape
+        if k_.shape != q_.shape or v_.shape != q_.shape:
+            raise NotImplementedError("sdpa: query, key and value must share the shape (B,T,d)")
+        if m_ is not None and m_.numel() != B * T:
+            raise NotImplementedError("sdpa: only the reference's query-row mask of shape (B,T,1) is supported")
+        nbytes = lib.mmt_sdpa_workspace_bytes(B, T, d, h)
+        if nbytes == 0:
+            _lib.check(lib.mmt_sdpa_forward(None, None, None, None, None, None, 0, B, T, d, h, None))
+        ws = _lib.POOL.get(nbytes, q_.device)
+        out = torch.empty_like(q_)
+        _lib.check(lib.mmt_sdpa_forward(_lib.ptr(q_), _lib.ptr(k_), _lib.ptr(v_), _lib.ptr(m_), _lib.ptr(out), _lib.ptr(ws), nbytes,
+                                        B, T, d, h, _lib.stream_ptr()))
+        if any(ctx.needs_input_grad):
+            ctx.ws, ctx.cfg, ctx.mask = ws, (B, T, d, h, nbytes), m_
+        else:
+            _lib.POOL.put(ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        lib = _lib.load()
+        B, T, d, h, nbytes = ctx.cfg
+        g = _f32c(dctx)
+        dq, dk, dv = (torch.empty_like(g) for _ in range(3))
+        _lib.check(lib.mmt_sdpa_backward(_lib.ptr(g), _lib.ptr(ctx.mask), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(ctx.ws),
+                                         nbytes, B, T, d, h, _lib.stream_ptr()))
+        _lib.POOL.put(ctx.ws)
+        ctx.ws = None
+        return dq, dk, dv, None, None
+
+
+def sdpa(q, k, v, mask, h):
+    """q,k,v: (B,T,d) with head i in columns [i*d/h,(i+1)*d/h); mask (B,T,1) blanks query rows; -> (B,T,d)."""
+    return _SdpaFn.apply(q, k, v, mask, int(h))
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, rowscale, act):
+        lib = _lib.load()
+        _lib.require_hip(x, W, b, rowscale)
+        x_, W_, b_, r_ = _f32c(x), _f32c(W), _f32c(b), _f32c(rowscale)
+        K = x_.shape[-1]
+        N = W_.shape[0]
+        M = x_.numel() // K
+        if W_.shape[1] != K:
+            raise ValueError("linear: weight %s does not match input features %d" % (tuple(W_.shape), K))
+        if r_ is not None and r_.numel() != M:
+            raise ValueError("linear: rowscale must have one entry per row")
+        nbytes = lib.mmt_linear_workspace_bytes(M, K, N)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=x_.device)
+        y = torch.empty(x_.shape[:-1] + (N,), dtype=torch.float32, device=x_.device)
+        _lib.check(lib.mmt_linear_forward(_lib.ptr(x_), _lib.ptr(W_), _lib.ptr(b_), _lib.ptr(r_), _lib.ptr(y), _lib.ptr(ws), nbytes,
+                                          M, K, N, act, _lib.stream_ptr()))
+        ctx.save_for_backward(x_, W_, y if act == 1 else None, r_)
+        ctx.cfg = (M, K, N, act, nbytes, b is not None)
+        ctx.ws = ws
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x_, W_, y_, r_ = ctx.saved_tensors
+        M, K, N, act, nbytes, has_b = ctx.cfg
+        g = _f32c(dy)
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x_) if need_x else None
+        dW = torch.empty_like(W_) if need_w else None
+        db = torch.empty(N, dtype=torch.float32, device=x_.device) if need_b else None
+        _lib.check(lib.mmt_linear_backward(_lib.ptr(g), _lib.ptr(x_), _lib.ptr(W_), _lib.ptr(y_), _lib.ptr(r_), _lib.ptr(dx),
+                                           _lib.ptr(dW), _lib.ptr(db), _lib.ptr(ctx.ws), nbytes, M, K, N, act, _lib.stream_ptr()))
+        ctx.ws = None
+        return dx, dW, db, None, None
+
+
+def linear(x, weight, bias=None, act=0, rowscale=None):
+    """y = act(x W^T + b) [* rowscale per row]; act: 0 none, 1 ReLU."""
+    return _LinearFn.apply(x, weight, bias, rowscale, int(act))

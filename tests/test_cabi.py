@@ -1,0 +1,73 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/mmt_hip.h declares; shape queries and argument validation work without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "mmt_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mmt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    from multimodal_transformer_amd import _lib
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), "libmmt_hip.so does not export %s" % name
+        assert name in _lib.SIGNATURES, "python binding lacks a signature for %s" % name
+    assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_shape_queries_and_validation():
+    from multimodal_transformer_amd import _lib
+    lib = _lib.load()
+    assert lib.mmt_abi_version() == 1
+    d, f, n = 128, 128, 6
+    per_layer = 4 * (d * d + d) + 2 * d * f + f + d + 4 * d
+    assert lib.mmt_encoder_param_count(d, f, n) == n * per_layer + 2 * d
+    assert lib.mmt_encoder_workspace_bytes(4, 50, 128, 8, 128, 2) > 0
+    assert lib.mmt_encoder_workspace_bytes(4, 50, 130, 8, 128, 2) == 0            # d % h != 0
+    assert b"divisible" in lib.mmt_last_error()
+    assert lib.mmt_encoder_workspace_bytes(4, 50, 512, 8, 128, 2) == 0            # d_k = 64 unsupported
+    assert b"d_k" in lib.mmt_last_error()
+    rc = lib.mmt_encoder_forward(None, None, None, None, None, 0, 4, 50, 128, 8, 128, 2, 1e-6, 0.0, 0, None)
+    assert rc == 1 and b"null" in lib.mmt_last_error()
+    assert lib.mmt_linear_workspace_bytes(10, 64, 3) > 0
+    assert lib.mmt_layernorm_scratch_floats(33, 40) == 2 * 2 * 64
+
+
+def test_state_dict_keys_match_reference_names():
+    """parameter names/shapes are the checkpoint contract."""
+    import torch
+    from multimodal_transformer_amd import multiTransformer as MT
+    enc = MT.Encoder(MT.EncoderLayer(40, MT.MultiHeadedAttention(4, 40), MT.PositionwiseFeedForward(40, 128, 0.1), 0.1), 2)
+    keys = list(enc.state_dict().keys())
+    want = []
+    for i in range(2):
+        for j in range(4):
+            want += ["layers.%d.self_attn.linears.%d.weight" % (i, j), "layers.%d.self_attn.linears.%d.bias" % (i, j)]
+        want += ["layers.%d.feed_forward.w_1.weight" % i, "layers.%d.feed_forward.w_1.bias" % i,
+                 "layers.%d.feed_forward.w_2.weight" % i, "layers.%d.feed_forward.w_2.bias" % i]
+        for j in range(2):
+            want += ["layers.%d.sublayer.%d.norm.a_2" % (i, j), "layers.%d.sublayer.%d.norm.b_2" % (i, j)]
+    want += ["norm.a_2", "norm.b_2"]
+    assert keys == want
+    assert [tuple(p.shape) for p in enc.flat_parameters()][:4] == [(40, 40), (40,), (40, 40), (40,)]
+    assert sum(p.numel() for p in enc.flat_parameters()) == sum(p.numel() for p in enc.parameters())
+    # layers are deep copies of one initialised layer => identical initial values (multiTransformer.py:78-79)
+    assert torch.equal(enc.layers[0].self_attn.linears[0].weight, enc.layers[1].self_attn.linears[0].weight)
+
+
+def test_cpu_call_fails_loudly():
+    import torch
+    from multimodal_transformer_amd import multiTransformer as MT
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        MT.LayerNorm(8)(torch.zeros(2, 8))

@@ -1,0 +1,277 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle and the golden fixtures.
+
+Stated tolerances.  The HIP path multiplies in bf16 (8-bit significand) with fp32 accumulation and keeps
+the residual stream, LayerNorm and softmax in fp32; the reference is all-fp32.  So the bar is not 1e-6:
+  * kernels without matrix products (LayerNorm): fp32 round-off — 2e-5 absolute, 2e-4 relative-L2 on grads;
+  * anything through bf16 MFMA: relative-L2 error <= OUT_RTOL on outputs and <= GRAD_RTOL on gradients
+    (per tensor, with an absolute floor for analytically-zero gradients), and CCC(out, ref) >= 1 - 1e-3
+    (the north-star bound on valence outputs);
+  * index/mask semantics are exact: outputs of blanked query rows equal the uniform-attention value
+    computed from the same bf16 operands, and model outputs are exactly 0 where mask == 0.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import recipe as R
+from conftest import load_golden, rel_l2, grad_close
+
+pytestmark = pytest.mark.gpu
+
+OUT_RTOL = 2e-2
+GRAD_RTOL = 4e-2
+CCC_MIN = 1 - 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def mta():
+    import multimodal_transformer_amd as m
+    return m
+
+
+def _report(tag, got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    r = rel_l2(got, ref)
+    print("%-44s rel_l2 %.3e  max_abs %.3e  ref_rms %.3e" % (tag, r, np.abs(got - ref).max(), np.sqrt((ref ** 2).mean())))
+    return r
+
+
+def _oracle_encoder(p32, x, mask, h, g):
+    """fp64 oracle forward/backward -> (out, dx, grads)."""
+    p = {k: v.double().clone().requires_grad_() for k, v in p32.items()}
+    xd = x.double().clone().requires_grad_()
+    y = oracle.encoder_stack(p, "", xd, mask.double(), h)
+    (y * g.double()).sum().backward()
+    return y.detach(), xd.grad, {k: v.grad for k, v in p.items()}
+
+
+def _build_encoder(d, h, n, dev, p32):
+    MT = mta().multiTransformer
+    enc = MT.Encoder(MT.EncoderLayer(d, MT.MultiHeadedAttention(h, d), MT.PositionwiseFeedForward(d, R.D_FF, 0.1), 0.1), n)
+    enc.load_state_dict(p32)
+    return enc.to(dev).eval()
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+def test_layernorm_matches_oracle_and_golden(dev):
+    fx = load_golden("ln_d128")
+    MT = mta().multiTransformer
+    ln = MT.LayerNorm(128)
+    p32 = R.gen_params(R.shapes_of(ln.state_dict()), R.SEED)
+    ln.load_state_dict(p32)
+    ln = ln.to(dev)
+    x = R.gen_normal("ln:x", (4, 50, 128), R.SEED)
+    g = R.gen_normal("ln:g", (4, 50, 128), R.SEED)
+    xg = x.to(dev).requires_grad_()
+    y = ln(xg)
+    (y * g.to(dev)).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), fx["out"], atol=2e-5, rtol=0)
+    assert _report("ln dx", xg.grad.cpu().numpy(), fx["dx"]) < 2e-4
+    assert _report("ln da", ln.a_2.grad.cpu().numpy(), fx["grad:a_2"]) < 2e-4
+    assert _report("ln db", ln.b_2.grad.cpu().numpy(), fx["grad:b_2"]) < 2e-4
+
+
+@pytest.mark.parametrize("M,d", [(1, 4), (33, 40), (200, 256), (7, 300)])
+def test_layernorm_shapes(dev, M, d):
+    x = R.gen_normal("lnshape:x%d" % d, (M, d), 3)
+    a = 1 + 0.1 * R.gen_normal("lnshape:a%d" % d, (d,), 3)
+    b = 0.1 * R.gen_normal("lnshape:b%d" % d, (d,), 3)
+    g = R.gen_normal("lnshape:g%d" % d, (M, d), 3)
+    xd, ad, bd = (t.double().requires_grad_() for t in (x, a, b))
+    yd = oracle.layer_norm(xd, ad, bd)
+    (yd * g.double()).sum().backward()
+    F = mta().functional
+    xg, ag, bg = (t.to(dev).requires_grad_() for t in (x, a, b))
+    y = F.layer_norm(xg, ag, bg)
+    (y * g.to(dev)).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yd.detach().numpy(), atol=3e-5, rtol=1e-5)
+    assert _report("ln%d dx" % d, xg.grad.cpu(), xd.grad) < 3e-4
+    assert _report("ln%d da" % d, ag.grad.cpu(), ad.grad) < 3e-4
+    assert _report("ln%d db" % d, bg.grad.cpu(), bd.grad) < 3e-4
+
+
+# ------------------------------------------------------------------------------------------ linear
+@pytest.mark.parametrize("M,K,N,act,rs", [(200, 128, 128, 0, False), (200, 128, 128, 1, False), (37, 300, 256, 0, False),
+                                          (64, 576, 64, 1, False), (200, 64, 1, 0, True), (50, 448, 128, 1, True),
+                                          (3, 4, 5, 0, False)])
+def test_linear(dev, M, K, N, act, rs):
+    tag = "lin%dx%dx%d" % (M, K, N)
+    x = R.gen_normal(tag + "x", (M, K), 5)
+    W = R.gen_normal(tag + "w", (N, K), 5) / np.sqrt(K)
+    b = 0.1 * R.gen_normal(tag + "b", (N,), 5)
+    g = R.gen_normal(tag + "g", (M, N), 5)
+    r = (R.gen_uniform(tag + "r", (M,), 5) > 0.3).float() if rs else None
+    # oracle on the bf16-rounded operands isolates accumulation-order error from operand rounding
+    xd, Wd, bd = (t.double().requires_grad_() for t in (x, W, b))
+    yd = xd @ Wd.t() + bd
+    if act:
+        yd = torch.relu(yd)
+    if rs:
+        yd = yd * r.double()[:, None]
+    (yd * g.double()).sum().backward()
+    F = mta().functional
+    xg, Wg, bg = (t.to(dev).requires_grad_() for t in (x, W, b))
+    y = F.linear(xg, Wg, bg, act=act, rowscale=None if r is None else r.to(dev))
+    (y * g.to(dev)).sum().backward()
+    assert y.shape == (M, N)
+    assert _report(tag + " y", y.detach().cpu(), yd.detach()) < OUT_RTOL
+    assert _report(tag + " dx", xg.grad.cpu(), xd.grad) < GRAD_RTOL
+    assert _report(tag + " dW", Wg.grad.cpu(), Wd.grad) < GRAD_RTOL
+    assert _report(tag + " db", bg.grad.cpu(), bd.grad) < GRAD_RTOL
+    if rs:
+        assert (y.detach().cpu()[r == 0] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------ attention core
+@pytest.mark.parametrize("B,T,d,h,lengths", [
+    (2, 50, 128, 8, [50, 20]), (3, 33, 40, 4, [33, 32, 1]), (2, 64, 256, 8, [64, 7]), (1, 1, 16, 1, [1]),
+    (2, 300, 40, 4, [300, 41]), (1, 500, 128, 8, [350]), (1, 257, 256, 8, [257])])
+def test_sdpa(dev, B, T, d, h, lengths):
+    tag = "sdpa%d_%d_%d" % (T, d, h)
+    q, k, v, g = (R.gen_normal(tag + n, (B, T, d), 7) for n in "qkvg")
+    q = q * 2.0                                          # spread the scores
+    mask = R.prefix_mask(lengths, T)
+    dk = d // h
+
+    def split(z):
+        return z.reshape(B, T, h, dk).permute(0, 2, 1, 3)
+
+    qd, kd, vd = (t.double().requires_grad_() for t in (q, k, v))
+    ctx, _ = oracle.scaled_dot_attention(split(qd), split(kd), split(vd), mask.double().unsqueeze(1))
+    ref = ctx.permute(0, 2, 1, 3).reshape(B, T, d)
+    (ref * g.double()).sum().backward()
+    F = mta().functional
+    qg, kg, vg = (t.to(dev).requires_grad_() for t in (q, k, v))
+    out = F.sdpa(qg, kg, vg, mask.to(dev), h)
+    (out * g.to(dev)).sum().backward()
+    assert _report(tag + " ctx", out.detach().cpu(), ref.detach()) < OUT_RTOL
+    floor = 3e-3 * float(vd.grad.abs().max())
+    for name, a, b_ in (("dq", qg.grad, qd.grad), ("dk", kg.grad, kd.grad), ("dv", vg.grad, vd.grad)):
+        _report(tag + " " + name, a.cpu(), b_)
+        assert grad_close(a.cpu().numpy(), b_.numpy(), GRAD_RTOL, floor), name
+    # index/mask semantics: a blanked query row is the plain mean of ALL T value rows (bf16-rounded values)
+    vb = v.to(torch.bfloat16).float()
+    for bi, n in enumerate(lengths):
+        if n < T:
+            mean_v = vb[bi].mean(dim=0)
+            got = out.detach().cpu()[bi, n:]
+            assert (got - mean_v).abs().max() < 2e-2 * max(1.0, float(mean_v.abs().max())) + 8e-3
+            assert (qg.grad.cpu()[bi, n:] == 0).all()          # blanked rows pass no gradient to q (exact)
+
+
+def test_sdpa_no_mask(dev):
+    q, k, v = (R.gen_normal("nomask" + n, (2, 40, 64), 9) for n in "qkv")
+    ctx, _ = oracle.scaled_dot_attention(*(t.double().reshape(2, 40, 4, 16).permute(0, 2, 1, 3) for t in (q, k, v)), None)
+    ref = ctx.permute(0, 2, 1, 3).reshape(2, 40, 64)
+    out = mta().functional.sdpa(q.to(dev), k.to(dev), v.to(dev), None, 4)
+    assert _report("sdpa nomask", out.cpu(), ref) < OUT_RTOL
+
+
+# ------------------------------------------------------------------------------------------ modules vs golden
+def test_multi_headed_attention_module(dev):
+    fx = load_golden("mha_d128_h8")
+    MT = mta().multiTransformer
+    mha = MT.MultiHeadedAttention(8, 128)
+    mha.load_state_dict(R.gen_params(R.shapes_of(mha.state_dict()), R.SEED))
+    mha = mha.to(dev).eval()
+    mask = R.prefix_mask(list(fx["lengths"]), 50).to(dev)
+    x = R.gen_normal("mha:x", (4, 50, 128), R.SEED).to(dev).requires_grad_()
+    g = R.gen_normal("mha:g", (4, 50, 128), R.SEED).to(dev)
+    y = mha(x, x, x, mask)
+    (y * g).sum().backward()
+    assert mha.attn is None
+    assert _report("mha out", y.detach().cpu(), fx["out"]) < OUT_RTOL
+    assert _report("mha dx", x.grad.cpu(), fx["dx"]) < GRAD_RTOL
+    scale = max(float(np.abs(fx[k]).max()) for k in fx if k.startswith("grad:"))
+    for n, p in mha.named_parameters():
+        _report("mha d" + n, p.grad.cpu(), fx["grad:" + n])
+        assert grad_close(p.grad.cpu().numpy(), fx["grad:" + n], GRAD_RTOL, 3e-3 * scale), n
+
+
+def test_feed_forward_module(dev):
+    fx = load_golden("ffn_d128")
+    MT = mta().multiTransformer
+    ffn = MT.PositionwiseFeedForward(128, R.D_FF, 0.1)
+    ffn.load_state_dict(R.gen_params(R.shapes_of(ffn.state_dict()), R.SEED))
+    ffn = ffn.to(dev).eval()
+    x = R.gen_normal("ffn:x", (4, 50, 128), R.SEED).to(dev).requires_grad_()
+    g = R.gen_normal("ffn:g", (4, 50, 128), R.SEED).to(dev)
+    y = ffn(x)
+    (y * g).sum().backward()
+    assert _report("ffn out", y.detach().cpu(), fx["out"]) < OUT_RTOL
+    assert _report("ffn dx", x.grad.cpu(), fx["dx"]) < GRAD_RTOL
+    for n, p in ffn.named_parameters():
+        assert _report("ffn d" + n, p.grad.cpu(), fx["grad:" + n]) < GRAD_RTOL, n
+
+
+@pytest.mark.parametrize("case", R.ENCODER_CASES, ids=[c[0] for c in R.ENCODER_CASES])
+def test_encoder_stack_golden(dev, case):
+    name, d, h, n, B, T, lengths = case
+    fx = load_golden(name)
+    MT = mta().multiTransformer
+    proto = MT.Encoder(MT.EncoderLayer(d, MT.MultiHeadedAttention(h, d), MT.PositionwiseFeedForward(d, R.D_FF, 0.1), 0.1), n)
+    p32 = R.gen_params(R.shapes_of(proto.state_dict()), R.SEED)
+    assert abs(R.weights_checksum(p32) - float(fx["checksum"])) <= 1e-6 * float(fx["checksum"])
+    enc = _build_encoder(d, h, n, dev, p32)
+    assert enc._fusable()
+    mask = R.prefix_mask(lengths, T)
+    x = R.gen_normal(name + ":x", (B, T, d), R.SEED)
+    g = R.gen_normal(name + ":g", (B, T, d), R.SEED)
+    xg = x.to(dev).requires_grad_()
+    y = enc(xg, mask.to(dev))
+    (y * g.to(dev)).sum().backward()
+    out = y.detach().cpu().numpy()
+    assert np.isfinite(out).all()
+    assert _report(name + " out", out, fx["out"]) < OUT_RTOL
+    ccc = mta().eval_ccc(fx["out"], out)
+    print("%-44s CCC %.6f" % (name, ccc))
+    assert ccc >= CCC_MIN
+    assert _report(name + " dx", xg.grad.cpu(), fx["dx"]) < GRAD_RTOL
+    scale = max(float(np.abs(fx[k]).max()) for k in fx if k.startswith("grad:"))
+    worst = 0.0
+    for pn, p in enc.named_parameters():
+        assert p.grad is not None, pn
+        ref = fx["grad:" + pn]
+        got = p.grad.cpu().numpy()
+        worst = max(worst, rel_l2(got, ref) if np.abs(ref).max() > 1e-3 * scale else 0.0)
+        assert grad_close(got, ref, GRAD_RTOL, 3e-3 * scale), pn
+    print("%-44s worst param-grad rel_l2 %.3e" % (name, worst))
+
+
+def test_encoder_fused_equals_layerwise(dev):
+    """The fused stack and the module-by-module composition (separate LayerNorm / linear / sdpa calls)
+    are two HIP routes through the same arithmetic: they must agree to bf16 round-off."""
+    d, h, n = 128, 8, 2
+    MT = mta().multiTransformer
+    proto = MT.Encoder(MT.EncoderLayer(d, MT.MultiHeadedAttention(h, d), MT.PositionwiseFeedForward(d, R.D_FF, 0.1), 0.1), n)
+    p32 = R.gen_params(R.shapes_of(proto.state_dict()), 11)
+    enc = _build_encoder(d, h, n, dev, p32)
+    x = R.gen_normal("fusedvs:x", (3, 40, d), 11).to(dev)
+    mask = R.prefix_mask([40, 25, 3], 40).to(dev)
+    y_fused = enc(x, mask)
+    y_layer = x
+    for layer in enc.layers:
+        y_layer = layer(y_layer, mask)
+    y_layer = enc.norm(y_layer)
+    assert _report("fused vs layerwise", y_fused.cpu(), y_layer.cpu()) < OUT_RTOL
+
+
+def test_cpu_tensors_are_refused():
+    MT = mta().multiTransformer
+    ln = MT.LayerNorm(8)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ln(torch.zeros(2, 8))
+
+
+def test_unsupported_head_dim_raises(dev):
+    F = mta().functional
+    q = torch.zeros(1, 4, 64, device=dev)
+    with pytest.raises(RuntimeError, match="d_k"):
+        F.sdpa(q, q, q, None, 1)
