@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Throughput of the attention hot path on MI355X: windows/sec, forward+backward.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One step = one forward + loss + backward pass (all input, weight and LayerNorm gradients) of the
+encoder stack over one synthetic batch already resident in HBM; with N>1 each rank holds its own
+B sequences (weak scaling) and the step ends with the RCCL SUM all-reduce of the gradients.
+A window is one time-step of one sequence: windows/step = N*B*T.
+
+Rank 0 prints ONE JSON line carrying, besides the contract fields,
+  roofline     — the dominant kernel of the step (by HIP-event time measured here, on the stream the
+                 kernels run on), its algorithmic FLOPs per launch / average duration vs the dense
+                 bf16 MFMA peak;
+  cpu_baseline — the CPU oracle (a port of the reference path, fp32 torch CPU) timed on this box's
+                 host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
+
+# per-GPU slices of the BASELINE.json configs (N=6, d_ff=128: constructor defaults of the reference)
+WORKLOADS = {
+    "C4": dict(desc="SFT encoder stack T=500 d_model=128 heads=8 N=6 d_ff=128, 32 sequences/GPU", B=32, T=500, d=128, h=8, N=6, f=128),
+    "C2": dict(desc="SFT encoder stack T=300 d_model=40 heads=4 N=6 d_ff=128, 32 sequences/GPU", B=32, T=300, d=40, h=4, N=6, f=128),
+    "C3e": dict(desc="MFT per-modality encoder stack T=300 d_model=256 heads=8 N=6 d_ff=128, 32 sequences/GPU", B=32, T=300, d=256, h=8, N=6, f=128),
+    "C5e": dict(desc="MFT per-modality encoder stack T=1000 d_model=256 heads=8 N=6 d_ff=128, 64 sequences/GPU", B=64, T=1000, d=256, h=8, N=6, f=128),
+}
+
+
+def flops_per_window_layer_fwd(d, T, f):
+    """Algorithmic matmul FLOPs per window per layer, forward: 8d^2 + 4Td + 4df."""
+    return 8 * d * d + 4 * T * d + 4 * d * f
+
+
+def site_flops_per_launch(site, M, T, d, f):
+    """Algorithmic FLOPs of one launch of a kernel site (no credit for recomputation)."""
+    table = {
+        "rowgemm<FRAG,LN>:ln1+qkv": 6 * d * d,
+        "attn_fwd_kernel": 4 * T * d,
+        "rowgemm<PLAIN>:outproj+res": 2 * d * d,
+        "rowgemm<PLAIN,LN>:ln2+ffn1+relu": 2 * d * f,
+        "rowgemm<PLAIN>:ffn2+res": 2 * d * f,
+        "rowgemm<PLAIN>:bwd_ffn2": 2 * d * f,
+        "rowgemm<LNBWD>:bwd_ffn1+ln2": 2 * d * f,
+        "rowgemm<FRAG>:bwd_outproj->dO": 2 * d * d,
+        "attn_bwd_kernel": 8 * T * d,
+        "rowgemm<LNBWD>:bwd_qkv+ln1": 6 * d * d,
+        "wgrad_kernel": 8 * d * d + 4 * d * f,
+    }
+    return table.get(site, 0) * M
+
+
+def build_encoder(cfg, dev):
+    from multimodal_transformer_amd import multiTransformer as MT
+    torch.manual_seed(1)                                    # transformer/SFT/train.py:522
+    enc = MT.Encoder(MT.EncoderLayer(cfg["d"], MT.MultiHeadedAttention(cfg["h"], cfg["d"]),
+                                     MT.PositionwiseFeedForward(cfg["d"], cfg["f"], 0.1), 0.1), cfg["N"])
+    return enc.to(dev)
+
+
+def cpu_baseline(cfg, seconds_budget=15.0):
+    """Oracle (port of the reference path) fwd+bwd on host cores, bounded sample of the same workload."""
+    import oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 16)          # the GPU box gives one GPU a 16-CPU share; more threads only oversubscribe it
+    torch.set_num_threads(cores)
+    from multimodal_transformer_amd import multiTransformer as MT
+    torch.manual_seed(1)
+    enc = MT.Encoder(MT.EncoderLayer(cfg["d"], MT.MultiHeadedAttention(cfg["h"], cfg["d"]),
+                                     MT.PositionwiseFeedForward(cfg["d"], cfg["f"], 0.1), 0.1), cfg["N"])
+    p = {k: v.detach().clone().requires_grad_() for k, v in enc.state_dict().items()}
+    Bs = max(1, min(cfg["B"], 4))
+    T, d = cfg["T"], cfg["d"]
+    x = torch.randn(Bs, T, d, requires_grad=True)
+    mask = torch.ones(Bs, T, 1)
+    tgt = torch.rand(Bs, T, d)
+
+    def step():
+        for v in p.values():
+            v.grad = None
+        x.grad = None
+        y = oracle.encoder_stack(p, "", x, mask, cfg["h"])
+        (((y - tgt) ** 2).sum() / (Bs * T)).backward()
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if time.perf_counter() - t0 > seconds_budget or n >= 10:
+            break
+    dt = (time.perf_counter() - t0) / n
+    return {"value": Bs * T / dt, "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of the CPU oracle (fp32 torch-CPU port of the reference path) on %d of the %d sequences, same T/d/h/N, "
+                      "eval-mode arithmetic; %.2f s/step" % (n, Bs, cfg["B"], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=5, help="extra eager steps with per-kernel HIP-event timing")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from multimodal_transformer_amd import _lib, parallel
+    cfg = WORKLOADS[args.workload]
+    B, T, d, h, N, f = (cfg[k] for k in ("B", "T", "d", "h", "N", "f"))
+    M = B * T
+    enc = build_encoder(cfg, dev).eval()       # eval-mode arithmetic: train-mode dropout kernels are not implemented yet
+    params = [p for p in enc.parameters()]
+    g = torch.Generator(device="cpu").manual_seed(1 + rank)
+    x = torch.randn(B, T, d, generator=g).to(dev).requires_grad_()
+    tgt = torch.rand(B, T, d, generator=g).to(dev)
+    mask = torch.ones(B, T, 1, device=dev)                   # throughput runs use full-length sequences (§8d)
+    nvalid = float(world * B * T)
+
+    def fwd_bwd():
+        for p in params:
+            p.grad = None
+        x.grad = None
+        y = enc(x, mask)
+        loss = ((y - tgt) ** 2).sum() / nvalid
+        loss.backward()
+        return loss
+
+    def step_eager():
+        fwd_bwd()
+        parallel.allreduce_gradients(params)
+
+    # ---- warm-up (also creates the pooled workspace before any capture)
+    for _ in range(max(1, args.warmup)):
+        step_eager()
+    torch.cuda.synchronize()
+
+    launch = "eager"
+    graph = None
+    if not args.no_graph:
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    fwd_bwd()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                fwd_bwd()
+            launch = "hipgraph"
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print("graph capture failed (%s); falling back to eager launches" % str(e).splitlines()[0], file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            parallel.allreduce_gradients(params)
+        else:
+            step_eager()
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * M * args.steps / elapsed
+
+    # ---- per-kernel timing (HIP events on the launch stream), eager, outside the timed region
+    roofline, kernel_ms = None, {}
+    if rank == 0 and args.profile_steps > 0:
+        _lib.profile(True)
+        for _ in range(args.profile_steps):
+            fwd_bwd()
+        torch.cuda.synchronize()
+        prof = _lib.profile_collect()
+        _lib.profile(False)
+        kernel_ms = {k: round(v[0] / args.profile_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        dom = max(prof.items(), key=lambda kv: kv[1][0])
+        name, (tot_ms, cnt) = dom
+        avg_s = tot_ms / cnt * 1e-3
+        fl = site_flops_per_launch(name, M, T, d, f)
+        ach = fl / avg_s / 1e12 if avg_s > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": None,
+                    "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": cnt // args.profile_steps,
+                    "flops_per_launch": fl,
+                    "share_of_kernel_time": round(tot_ms / sum(v[0] for v in prof.values()), 3)}
+
+    if rank == 0:
+        fpw = 3 * N * flops_per_window_layer_fwd(d, T, f)
+        out = {
+            "metric": "windows/sec fwd+bwd", "value": round(value, 1), "unit": "windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": cfg["desc"] + "; fwd + MSE loss + bwd (input, weight, LayerNorm grads)"
+                       + ("; + RCCL SUM all-reduce of gradients" if world > 1 else ""),
+                       "name": args.workload, "global_batch": world * B, "seq_len": T, "d_model": d, "heads": h, "layers": N, "d_ff": f,
+                       "parallelism": "dp%d" % world, "dropout": "off (eval-mode arithmetic; train-mode dropout kernels not implemented yet)",
+                       "lengths": "full"},
+            "launch": launch,
+            "algorithmic_mflop_per_window": round(fpw / 1e6, 3),
+            "step_mfma_frac": round(value * fpw / (world * MFMA_BF16_PEAK_TFLOPS * 1e12), 5),
+            "roofline": roofline,
+            "kernel_ms_per_step": kernel_ms,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

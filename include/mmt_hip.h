@@ -37,6 +37,15 @@ typedef void* mmt_stream_t; /* hipStream_t */
 int mmt_abi_version(void);
 const char* mmt_last_error(void);
 
+/* ---- Per-launch-site timing with HIP events on the caller's stream (eager mode only: do not enable
+ * while capturing a hipGraph).  Used by bench.py for the roofline of the dominant kernel. */
+int mmt_profile_enable(int on);
+int mmt_profile_reset(void);
+int mmt_profile_num_sites(void);
+const char* mmt_profile_site_name(int site);
+/* waits for the recorded events; total_ms[num_sites], launches[num_sites] */
+int mmt_profile_collect(float* total_ms, int* launches);
+
 /* ---- Encoder stack: N x (pre-norm self-attention sublayer + pre-norm FFN sublayer) + final LayerNorm.
  * Replaces Encoder.forward(x, mask)                       transformer/MFT/multiTransformer.py:73-76
  *   with EncoderLayer.forward / SublayerConnection.forward                              :103-104,114-116

@@ -19,6 +19,11 @@ _P, _F, _I, _SZ, _U64 = _c.c_void_p, _c.c_float, _c.c_int, _c.c_size_t, _c.c_uin
 SIGNATURES = {
     "mmt_abi_version": (_I, []),
     "mmt_last_error": (_c.c_char_p, []),
+    "mmt_profile_enable": (_I, [_I]),
+    "mmt_profile_reset": (_I, []),
+    "mmt_profile_num_sites": (_I, []),
+    "mmt_profile_site_name": (_c.c_char_p, [_I]),
+    "mmt_profile_collect": (_I, [_P, _P]),
     "mmt_encoder_param_count": (_SZ, [_I, _I, _I]),
     "mmt_encoder_workspace_bytes": (_SZ, [_I] * 6),
     "mmt_encoder_forward": (_I, [_P, _P, _P, _P, _P, _SZ] + [_I] * 6 + [_F, _F, _U64, _P]),
@@ -112,3 +117,19 @@ class WorkspacePool:
 
 
 POOL = WorkspacePool()
+
+
+def profile(on):
+    lib = load()
+    lib.mmt_profile_reset()
+    lib.mmt_profile_enable(1 if on else 0)
+
+
+def profile_collect():
+    """-> {site name: (total_ms, launches)} for every site that ran since the last reset."""
+    lib = load()
+    n = lib.mmt_profile_num_sites()
+    ms = (ctypes.c_float * n)()
+    cnt = (ctypes.c_int * n)()
+    check(lib.mmt_profile_collect(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p)))
+    return {lib.mmt_profile_site_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n) if cnt[i]}

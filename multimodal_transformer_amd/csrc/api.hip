@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "../../include/mmt_hip.h"
 #include "common.h"
@@ -23,6 +24,55 @@ static int fail(int code, const char* fmt, ...) {
     return fail(MMT_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 #define LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) \
     return fail(MMT_EHIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); } while (0)
+
+// ------------------------------------------------------------------------------------ per-kernel timing
+// Optional HIP-event bracket around every launch site (eager mode only), so bench.py can report the
+// dominant kernel's average duration on the stream the kernels really run on.
+enum Site { S_PREP = 0, S_LN1_QKV, S_ATTN_FWD, S_OUTPROJ, S_LN2_FFN1, S_FFN2, S_LN_FWD, S_LN_BWD, S_BWD_FFN2, S_BWD_FFN1_LN2,
+            S_BWD_OUTPROJ, S_ATTN_BWD, S_DQ_FINISH, S_BWD_QKV_LN1, S_WGRAD, S_FINALIZE, S_OTHER, S_COUNT };
+static const char* const g_site_names[S_COUNT] = {
+    "encoder_prep_kernel", "rowgemm<FRAG,LN>:ln1+qkv", "attn_fwd_kernel", "rowgemm<PLAIN>:outproj+res",
+    "rowgemm<PLAIN,LN>:ln2+ffn1+relu", "rowgemm<PLAIN>:ffn2+res", "layernorm_fwd_kernel", "layernorm_bwd_kernel",
+    "rowgemm<PLAIN>:bwd_ffn2", "rowgemm<LNBWD>:bwd_ffn1+ln2", "rowgemm<FRAG>:bwd_outproj->dO", "attn_bwd_kernel",
+    "dq_finish_kernel", "rowgemm<LNBWD>:bwd_qkv+ln1", "wgrad_kernel", "finalize_kernels", "other"};
+struct ProfRec { int site; hipEvent_t a, b; };
+static bool g_prof = false;
+static ProfRec* g_recs = nullptr;
+static int g_nrec = 0, g_cap = 0;
+struct ProfScope {
+    hipStream_t st; int idx;
+    ProfScope(int site, hipStream_t s) : st(s), idx(-1) {
+        if (!g_prof) return;
+        if (g_nrec == g_cap) {
+            const int ncap = g_cap ? g_cap * 2 : 1024;
+            ProfRec* n = static_cast<ProfRec*>(realloc(g_recs, sizeof(ProfRec) * ncap));
+            if (!n) return;
+            for (int i = g_cap; i < ncap; ++i) { n[i].a = nullptr; n[i].b = nullptr; }
+            g_recs = n; g_cap = ncap;
+        }
+        ProfRec& r = g_recs[g_nrec];
+        if (!r.a && (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess)) return;
+        r.site = site; idx = g_nrec++;
+        hipEventRecord(r.a, st);
+    }
+    ~ProfScope() { if (idx >= 0) hipEventRecord(g_recs[idx].b, st); }
+};
+
+extern "C" int mmt_profile_enable(int on) { g_prof = on != 0; return MMT_OK; }
+extern "C" int mmt_profile_reset(void) { g_nrec = 0; return MMT_OK; }
+extern "C" int mmt_profile_num_sites(void) { return S_COUNT; }
+extern "C" const char* mmt_profile_site_name(int site) { return (site >= 0 && site < S_COUNT) ? g_site_names[site] : ""; }
+extern "C" int mmt_profile_collect(float* total_ms, int* launches) {
+    if (!total_ms || !launches) return fail(MMT_EINVAL, "null pointer argument");
+    for (int i = 0; i < S_COUNT; ++i) { total_ms[i] = 0.f; launches[i] = 0; }
+    for (int i = 0; i < g_nrec; ++i) {
+        HIP_TRY(hipEventSynchronize(g_recs[i].b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g_recs[i].a, g_recs[i].b));
+        total_ms[g_recs[i].site] += ms; launches[g_recs[i].site] += 1;
+    }
+    return MMT_OK;
+}
 
 extern "C" int mmt_abi_version(void) { return 1; }
 extern "C" const char* mmt_last_error(void) { return g_err; }
@@ -120,7 +170,7 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
 
 // ------------------------------------------------------------------------------------ launch helpers
 template <int EPI, bool LN>
-static int launch_rowgemm(const RowGemmParams& p, hipStream_t st) {
+static int launch_rowgemm(const RowGemmParams& p, hipStream_t st, int site = S_OTHER) {
     const size_t lds = rowgemm_lds_bytes(EPI, LN, p.KP, p.NP);
     if (lds > 160 * 1024) return fail(MMT_EUNSUPPORTED, "row GEMM tile needs %zu B of LDS (K=%d, N=%d)", lds, p.K, p.N);
     static size_t configured = 0;           // per instantiation
@@ -130,6 +180,7 @@ static int launch_rowgemm(const RowGemmParams& p, hipStream_t st) {
         configured = 160 * 1024;
     }
     const int grid = (p.M + 31) / 32;
+    ProfScope prof(site, st);
     hipLaunchKernelGGL((rowgemm_kernel<EPI, LN>), dim3(grid), dim3(MMT_THREADS), lds, st, p);
     LAUNCH_CHECK("rowgemm_kernel");
     return MMT_OK;
@@ -140,6 +191,7 @@ static RowGemmParams rg_zero() { RowGemmParams p; memset(&p, 0, sizeof(p)); retu
 static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* VT, bf16* ctx, bf16* ctxT, float* lse,
                            const EncDims& D, hipStream_t st) {
     dim3 grid((D.nt + 3) / 4, D.B * D.h);
+    ProfScope prof(S_ATTN_FWD, st);
     if (DKP == 16) hipLaunchKernelGGL((attn_fwd_kernel<16>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, D.h, D.T, D.nt, D.L.HDP, D.MP);
     else hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, D.h, D.T, D.nt, D.L.HDP, D.MP);
     LAUNCH_CHECK("attn_fwd_kernel");
@@ -150,6 +202,7 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
                            const bf16* dOR, const bf16* dOT, const float* lse, const float* delta, float* dqslab,
                            bf16* dkv, bf16* dkvT, const EncDims& D, hipStream_t st) {
     dim3 grid(D.nkb, D.B * D.h);
+    ProfScope prof(S_ATTN_BWD, st);
     if (DKP == 16)
         hipLaunchKernelGGL((attn_bwd_kernel<16, KT_BWD>), grid, dim3(MMT_THREADS), 0, st, QR, QT, KR, KT_, VR, dOR, dOT, lse, delta,
                            dqslab, dkv, D.L.NQ, dkvT, D.MP, D.h, D.T, D.nt, D.M, D.L.HDP);
@@ -198,6 +251,7 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
     const LayerLayout& L = D.L;
 
     if (D.N > 0) {
+        ProfScope prof(S_PREP, st);
         hipLaunchKernelGGL(encoder_prep_kernel, dim3(grid_for(L.pstride() + L.qstride()), D.N), dim3(256), 0, st,
                            params, W.wprep, W.bprep, L);
         LAUNCH_CHECK("encoder_prep_kernel");
@@ -218,7 +272,7 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
             p.fragT[0] = w.QT; p.fragT[1] = w.KT; p.fragT[2] = w.VT;
             p.T = T; p.Tp = D.Tp; p.h = h; p.DKP = L.DKP; p.nwhich = 3;
             p.rowmask = mask; p.qscale = LOG2E / sqrtf((float)L.dk); p.scale_first = 1;
-            if ((rc = launch_rowgemm<EPI_FRAG, true>(p, st))) return rc;
+            if ((rc = launch_rowgemm<EPI_FRAG, true>(p, st, S_LN1_QKV))) return rc;
         }
         if ((rc = launch_attn_fwd(L.DKP, w.QR, w.KR, w.VT, w.ctx, w.ctxT, w.lse, D, st))) return rc;
         {   // output projection + residual
@@ -227,7 +281,7 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
             p.A = w.ctx; p.a_bf16 = 1; p.lda = L.HDP;
             p.W = wp + L.pWo(); p.bias = bp + L.qbo();
             p.residual = xin; p.ldr = d; p.out_f32 = w.x1; p.ldo = d;
-            if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st))) return rc;
+            if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st, S_OUTPROJ))) return rc;
         }
         {   // LayerNorm 2 + first FFN product + ReLU
             RowGemmParams p = rg_zero();
@@ -236,7 +290,7 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
             p.ln_a = P + L.oln(2); p.ln_b = P + L.oln(3); p.eps = eps; p.stats = w.stats2;
             p.W = wp + L.pW1(); p.bias = bp + L.qb1(); p.act = 1;
             p.out_bf16 = w.hid; p.ldo16 = L.FP; p.n_store16 = L.FP; p.out_T = w.hidT; p.ldoT = D.MP;
-            if ((rc = launch_rowgemm<EPI_PLAIN, true>(p, st))) return rc;
+            if ((rc = launch_rowgemm<EPI_PLAIN, true>(p, st, S_LN2_FFN1))) return rc;
         }
         {   // second FFN product + residual
             RowGemmParams p = rg_zero();
@@ -244,11 +298,12 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
             p.A = w.hid; p.a_bf16 = 1; p.lda = L.FP;
             p.W = wp + L.pW2(); p.bias = bp + L.qb2();
             p.residual = w.x1; p.ldr = d; p.out_f32 = w.xout; p.ldo = d;
-            if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st))) return rc;
+            if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st, S_FFN2))) return rc;
         }
         xin = w.xout;
     }
     const float* Pf = params + (size_t)D.N * L.stride();
+    ProfScope prof(S_LN_FWD, st);
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(D.G), dim3(MMT_THREADS), 0, st, xin, Pf, Pf + d, eps, y, W.statsf, D.M, d);
     LAUNCH_CHECK("layernorm_fwd_kernel");
     return MMT_OK;
@@ -264,6 +319,7 @@ static int launch_ln_bwd(const float* dy, const float* x, const float* a, const 
         configured = true;
     }
     if (lds > 160 * 1024) return fail(MMT_EUNSUPPORTED, "LayerNorm width %d too large", d);
+    ProfScope prof(S_LN_BWD, st);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + 31) / 32), dim3(MMT_THREADS), lds, st, dy, x, a, stats, eps, dx, colpart, M, d, DP);
     LAUNCH_CHECK("layernorm_bwd_kernel");
     return MMT_OK;
@@ -291,7 +347,7 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
     const float* x_last = (D.N > 0) ? W.lw[D.N - 1].xout : x;
     float* cur = (D.N > 0) ? W.dxa : dx;
     if ((rc = launch_ln_bwd(dy, x_last, Pf, W.statsf, eps, cur, W.lnpart1, D.M, d, L.DP, st))) return rc;
-    hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, st, W.lnpart1, D.G, L.DP, d, gPf, gPf + d);
+    hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 31) / 32, 2), dim3(1024), 0, st, W.lnpart1, D.G, L.DP, d, gPf, gPf + d);
     LAUNCH_CHECK("ln_param_finalize_kernel");
 
     float* other = W.dxb;
@@ -308,7 +364,7 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             p.W = wp + L.pW2T();
             p.relu_mask = w.hid; p.ldm = L.FP;
             p.out_bf16 = W.dh; p.ldo16 = L.FP; p.n_store16 = L.FP; p.out_T = W.dhT; p.ldoT = D.MP;
-            if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st))) return rc;
+            if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st, S_BWD_FFN2))) return rc;
         }
         {   // dx1 = dx2 + LN2bwd(dh W1)
             RowGemmParams p = rg_zero();
@@ -317,7 +373,7 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             p.W = wp + L.pW1T();
             p.x = w.x1; p.ldx = d; p.st = w.stats2; p.ln_a = P + L.oln(2); p.eps = eps; p.d_real = d;
             p.dres = cur; p.lddres = d; p.out_f32 = other; p.ldo = d; p.colpart = W.lnpart2;
-            if ((rc = launch_rowgemm<EPI_LNBWD, false>(p, st))) return rc;
+            if ((rc = launch_rowgemm<EPI_LNBWD, false>(p, st, S_BWD_FFN1_LN2))) return rc;
         }
         {   // dO = dx1 Wo -> fragments + delta     [also emits dx1^T for dWo]
             RowGemmParams p = rg_zero();
@@ -327,12 +383,15 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             p.fragR[0] = W.dOR; p.fragT[0] = W.dOT;
             p.T = T; p.Tp = D.Tp; p.h = h; p.DKP = L.DKP; p.nwhich = 1;
             p.ctx = w.ctx; p.ldctx = L.HDP; p.delta = W.delta;
-            if ((rc = launch_rowgemm<EPI_FRAG, false>(p, st))) return rc;
+            if ((rc = launch_rowgemm<EPI_FRAG, false>(p, st, S_BWD_OUTPROJ))) return rc;
         }
         if ((rc = launch_attn_bwd(L.DKP, w.QR, w.QT, w.KR, w.KT, w.VR, W.dOR, W.dOT, w.lse, W.delta, W.dqslab,
                                   W.dqkv, W.dqkvT, D, st))) return rc;
-        hipLaunchKernelGGL(dq_finish_kernel, dim3(grid_for((size_t)D.M * L.HD / 4)), dim3(256), 0, st,
-                           W.dqslab, D.nkb, mask, 1.0f / sqrtf((float)L.dk), W.dqkv, L.NQ, W.dqkvT, D.MP, D.M, L.HD, L.HDP);
+        {
+            ProfScope prof(S_DQ_FINISH, st);
+            hipLaunchKernelGGL(dq_finish_kernel, dim3(grid_for((size_t)D.M * L.HD / 4)), dim3(256), 0, st,
+                               W.dqslab, D.nkb, mask, 1.0f / sqrtf((float)L.dk), W.dqkv, L.NQ, W.dqkvT, D.MP, D.M, L.HD, L.HDP);
+        }
         LAUNCH_CHECK("dq_finish_kernel");
         float* dxin = (l > 0) ? cur : dx;
         {   // dx = dx1 + LN1bwd(dQKV Wqkv)
@@ -342,7 +401,7 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             p.W = wp + L.pWqkvT();
             p.x = xin; p.ldx = d; p.st = w.stats1; p.ln_a = P + L.oln(0); p.eps = eps; p.d_real = d;
             p.dres = other; p.lddres = d; p.out_f32 = dxin; p.ldo = d; p.colpart = W.lnpart1;
-            if ((rc = launch_rowgemm<EPI_LNBWD, false>(p, st))) return rc;
+            if ((rc = launch_rowgemm<EPI_LNBWD, false>(p, st, S_BWD_QKV_LN1))) return rc;
         }
         {   // weight gradients of the layer
             WgradJobs J; memset(&J, 0, sizeof(J));
@@ -357,17 +416,21 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             add(1, W.dx1T, w.ctxT, W.sWo, W.sbo, L.DP, L.HDP);
             add(2, W.dhT, w.xn2T, W.sW1, W.sb1, L.FP, L.DP);
             add(3, W.dx2T, w.hidT, W.sW2, W.sb2, L.DP, L.FP);
-            hipLaunchKernelGGL(wgrad_kernel, dim3(t0, D.nsplit), dim3(MMT_THREADS), 0, st, J);
+            {
+                ProfScope prof(S_WGRAD, st);
+                hipLaunchKernelGGL(wgrad_kernel, dim3(t0, D.nsplit), dim3(MMT_THREADS), 0, st, J);
+            }
             LAUNCH_CHECK("wgrad_kernel");
+            ProfScope prof(S_FINALIZE, st);
             LayerSlabs S;
             S.dWqkv = W.sWqkv; S.dbqkv = W.sbqkv; S.dWo = W.sWo; S.dbo = W.sbo;
             S.dW1 = W.sW1; S.db1 = W.sb1; S.dW2 = W.sW2; S.db2 = W.sb2;
             S.ln1part = W.lnpart1; S.ln2part = W.lnpart2; S.nsplit = D.nsplit; S.G = D.G;
             hipLaunchKernelGGL(encoder_finalize_kernel, dim3(grid_for(L.oln(0))), dim3(256), 0, st, S, L, gP);
             LAUNCH_CHECK("encoder_finalize_kernel");
-            hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, st, W.lnpart1, D.G, L.DP, d,
+            hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 31) / 32, 2), dim3(1024), 0, st, W.lnpart1, D.G, L.DP, d,
                                gP + L.oln(0), gP + L.oln(1));
-            hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, st, W.lnpart2, D.G, L.DP, d,
+            hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 31) / 32, 2), dim3(1024), 0, st, W.lnpart2, D.G, L.DP, d,
                                gP + L.oln(2), gP + L.oln(3));
             LAUNCH_CHECK("ln_param_finalize_kernel");
         }
@@ -402,7 +465,7 @@ extern "C" int mmt_layernorm_backward(const float* dy, const float* x, const flo
     const int DP = round_up(d, 64), G = (M + 31) / 32;
     int rc = launch_ln_bwd(dy, x, a_2, stats, eps, dx, scratch, M, d, DP, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 255) / 256), dim3(256), 0, st, scratch, G, DP, d, da_2, db_2);
+    hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 31) / 32, 2), dim3(1024), 0, st, scratch, G, DP, d, da_2, db_2);
     LAUNCH_CHECK("ln_param_finalize_kernel");
     return MMT_OK;
 }

@@ -328,12 +328,23 @@ __global__ void encoder_finalize_kernel(LayerSlabs S, LayerLayout L, float* __re
     }
 }
 
-// LayerNorm parameter gradients: out_a[c] = sum_g part[g][1][c], out_b[c] = sum_g part[g][0][c]
-__global__ void ln_param_finalize_kernel(const float* __restrict__ part, int G, int DP, int d,
-                                         float* __restrict__ out_a, float* __restrict__ out_b) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d) return;
-    float sa = 0.f, sb = 0.f;
-    for (int g = 0; g < G; ++g) { sb += part[(size_t)g * 2 * DP + c]; sa += part[(size_t)g * 2 * DP + DP + c]; }
-    out_a[c] = sa; out_b[c] = sb;
+// LayerNorm parameter gradients: out_a[c] = sum_g part[g][1][c], out_b[c] = sum_g part[g][0][c].
+// grid = (DP/32, 2 {b,a}); 1024 threads = 32 columns x 32 row groups, coalesced 128-byte row reads,
+// fixed summation order (deterministic).
+__global__ __launch_bounds__(1024) void ln_param_finalize_kernel(const float* __restrict__ part, int G, int DP, int d,
+                                                                 float* __restrict__ out_a, float* __restrict__ out_b) {
+    __shared__ float red[32][33];
+    const int cx = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx, which = blockIdx.y;
+    float s = 0.f;
+    if (c < DP)
+        for (int g = rg; g < G; g += 32) s += part[(size_t)g * 2 * DP + (size_t)which * DP + c];
+    red[rg][cx] = s;
+    __syncthreads();
+    if (rg == 0 && c < d) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += red[i][cx];
+        (which ? out_a : out_b)[c] = t;
+    }
 }
