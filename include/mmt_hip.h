@@ -96,14 +96,46 @@ int mmt_sdpa_backward(const float* dctx, const float* mask, float* dq, float* dk
 /* ---- Fused affine map  y = act(x W^T + b) [* rowscale] on bf16 MFMA.
  * Replaces nn.Linear (+ F.relu) call sites of the path: PositionwiseFeedForward (:15-20), the four
  * attention projections (:43,55,65), embeds and read-out MLPs (:270,296,340-342,400-402).
- * x (M,K), W (N,K), b (N) or NULL, y (M,N), all fp32; act: 0 none, 1 ReLU; rowscale (M) or NULL. */
+ * x (M,K), W (N,K), b (N) or NULL, y (M,N), all fp32; act: 0 none, 1 ReLU, 2 tanh, 3 sigmoid; rowscale (M) or NULL. */
 size_t mmt_linear_workspace_bytes(int M, int K, int N);
 int mmt_linear_forward(const float* x, const float* W, const float* b, const float* rowscale, float* y,
                        void* workspace, size_t workspace_bytes, int M, int K, int N, int act, mmt_stream_t stream);
-/* dx (M,K) or NULL; dW (N,K), db (N) or NULL.  `y` is the forward output (ReLU mask source when act==1). */
+/* dx (M,K) or NULL; dW (N,K), db (N) or NULL.  `y` is the forward output (activation-derivative source when act != 0). */
 int mmt_linear_backward(const float* dy, const float* x, const float* W, const float* y, const float* rowscale,
                         float* dx, float* dW, float* db,
                         void* workspace, size_t workspace_bytes, int M, int K, int N, int act, mmt_stream_t stream);
+
+/* ---- LSTM recurrence over T steps with the input projection already applied.
+ * Replaces the per-step nn.LSTMCell loop of MFN.forward       transformer/MFT/multiTransformer.py:200-208
+ * and the per-step nn.LSTM call of the SFT decoder            transformer/SFT/multiTransformer.py:471-476.
+ * gx (T,B,4H) = x_t W_ih^T + b_ih + b_hh (gate order i,f,g,o); W_rec (4H,H) multiplies h_{t-1};
+ * h0,c0 (B,H) or NULL (zeros).  Outputs h_all, c_all (T,B,H) and the gate activations acts (T,B,4H)
+ * kept for the backward.  H % 4 == 0, H <= 256.  act codes elsewhere: 0 none, 1 ReLU, 2 tanh, 3 sigmoid. */
+size_t mmt_lstm_scan_workspace_bytes(int H);
+int mmt_lstm_scan_forward(const float* gx, const float* W_rec, const float* h0, const float* c0,
+                          float* h_all, float* c_all, float* acts, void* workspace, size_t workspace_bytes,
+                          int T, int B, int H, mmt_stream_t stream);
+/* dh_all, dc_all: gradients on the (T,B,H) outputs (either may be NULL).  dgx (T,B,4H) is the gradient of gx
+ * (also the operand of the batched dW_ih / dW_rec products); dh0, dc0 (B,H) or NULL. */
+int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, const float* W_rec, const float* c0,
+                           const float* c_all, const float* acts, float* dgx, float* dh0, float* dc0,
+                           void* workspace, size_t workspace_bytes, int T, int B, int H, mmt_stream_t stream);
+
+/* ---- MFN delta-memory recurrence.  Replaces the memory update inside MFN.forward's time loop
+ *                                                             transformer/MFT/multiTransformer.py:221-224
+ * apre (T,B,128): gamma{1,2}_fc1 applied to the `attended` part of `both` (+bias), rows [gamma1(64); gamma2(64)];
+ * Wm (128,128): the memory columns of gamma{1,2}_fc1.weight stacked the same way; W2 (2,128,64), b2 (2,128):
+ * gamma{1,2}_fc2; chat (T,B,128) = cHat.  Outputs mem_all (T,B,128) and u_all (T,B,128), g_all (T,B,256) kept
+ * for the backward.  mem_dim must be 128 and h_gamma 64 (the reference's constants, :133,140-141). */
+size_t mmt_mfn_mem_scan_workspace_bytes(void);
+int mmt_mfn_mem_scan_forward(const float* apre, const float* chat, const float* Wm, const float* W2, const float* b2,
+                             float* mem_all, float* u_all, float* g_all, void* workspace, size_t workspace_bytes,
+                             int T, int B, int mem_dim, int h_gamma, mmt_stream_t stream);
+/* dmem_all (T,B,128) or NULL -> dchat (T,B,128), dapre (T,B,128), dz_all (T,B,256) (pre-sigmoid gate gradients). */
+int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* chat, const float* mem_all, const float* u_all,
+                              const float* g_all, const float* Wm, const float* W2,
+                              float* dchat, float* dapre, float* dz_all, void* workspace, size_t workspace_bytes,
+                              int T, int B, int mem_dim, int h_gamma, mmt_stream_t stream);
 
 #ifdef __cplusplus
 }

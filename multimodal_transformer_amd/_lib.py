@@ -37,6 +37,12 @@ SIGNATURES = {
     "mmt_linear_workspace_bytes": (_SZ, [_I] * 3),
     "mmt_linear_forward": (_I, [_P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_P]),
     "mmt_linear_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_P]),
+    "mmt_lstm_scan_workspace_bytes": (_SZ, [_I]),
+    "mmt_lstm_scan_forward": (_I, [_P] * 8 + [_SZ] + [_I] * 3 + [_P]),
+    "mmt_lstm_scan_backward": (_I, [_P] * 10 + [_SZ] + [_I] * 3 + [_P]),
+    "mmt_mfn_mem_scan_workspace_bytes": (_SZ, []),
+    "mmt_mfn_mem_scan_forward": (_I, [_P] * 9 + [_SZ] + [_I] * 4 + [_P]),
+    "mmt_mfn_mem_scan_backward": (_I, [_P] * 11 + [_SZ] + [_I] * 4 + [_P]),
 }
 
 _lib = None

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmt_hip.so")
 SOURCES = ["api.hip"]
-HEADERS = ["common.h", "rowgemm.h", "attn.h", "misc_kernels.h"]
+HEADERS = ["common.h", "rowgemm.h", "attn.h", "misc_kernels.h", "scan.h"]
 
 
 def needs_build():

@@ -13,6 +13,7 @@
 #include "rowgemm.h"
 #include "attn.h"
 #include "misc_kernels.h"
+#include "scan.h"
 
 // ------------------------------------------------------------------------------------ error plumbing
 static thread_local char g_err[512] = "";
@@ -589,7 +590,9 @@ __global__ void grad_prep_kernel(const float* __restrict__ dy, const float* __re
         if (n < N) {
             v = dy[(size_t)m * N + n];
             if (rowscale) v *= rowscale[m];
-            if (act == 1 && !(y[(size_t)m * N + n] > 0.f)) v = 0.f;
+            if (act == 1) { if (!(y[(size_t)m * N + n] > 0.f)) v = 0.f; }
+            else if (act == 2) { const float yy = y[(size_t)m * N + n]; v *= 1.f - yy * yy; }
+            else if (act == 3) { const float yy = y[(size_t)m * N + n]; v *= yy * (1.f - yy); }
         }
         const bf16 o = (bf16)v;
         g[idx] = o;
@@ -663,7 +666,7 @@ extern "C" int mmt_linear_backward(const float* dy, const float* x, const float*
                                    void* workspace, size_t workspace_bytes, int M, int K, int N, int act, mmt_stream_t stream) {
     int rc = check_linear(M, K, N);
     if (rc) return rc;
-    if (!dy || !x || !Wt || !workspace || (act == 1 && !y)) return fail(MMT_EINVAL, "null pointer argument");
+    if (!dy || !x || !Wt || !workspace || (act != 0 && !y)) return fail(MMT_EINVAL, "null pointer argument");
     LinWs W; carve_linear(W, M, K, N, workspace);
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -691,5 +694,118 @@ extern "C" int mmt_linear_backward(const float* dy, const float* x, const float*
         if (db) hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for((size_t)N)), dim3(256), 0, st, W.sb, W.nsplit, 1, W.NP, db, 1, N);
         LAUNCH_CHECK("slab_sum_kernel");
     }
+    return MMT_OK;
+}
+
+
+// ------------------------------------------------------------------------------------ LSTM scan
+struct LstmWs { bf16 *Wf, *Wb; int HP16, KP, KP4; size_t bytes; };
+static int carve_lstm(LstmWs& W, int H, void* base) {
+    if (H <= 0 || H > 256) return fail(MMT_EUNSUPPORTED, "LSTM hidden size %d not in [4,256]", H);
+    if (H % 4) return fail(MMT_EUNSUPPORTED, "LSTM hidden size %d must be a multiple of 4", H);
+    W.HP16 = round_up(H, 16); W.KP = round_up(W.HP16, 32); W.KP4 = 4 * W.HP16;
+    Carver c(base);
+    W.Wf = c.take<bf16>((size_t)4 * W.HP16 * W.KP); W.Wb = c.take<bf16>((size_t)W.HP16 * W.KP4);
+    W.bytes = c.off;
+    return MMT_OK;
+}
+extern "C" size_t mmt_lstm_scan_workspace_bytes(int H) { LstmWs W; return carve_lstm(W, H, nullptr) ? 0 : W.bytes; }
+
+template <typename K> static int set_lds_attr(K kernel) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return MMT_OK;
+}
+
+extern "C" int mmt_lstm_scan_forward(const float* gx, const float* W_rec, const float* h0, const float* c0,
+                                     float* h_all, float* c_all, float* acts, void* workspace, size_t workspace_bytes,
+                                     int T, int B, int H, mmt_stream_t stream) {
+    if (!gx || !W_rec || !h_all || !c_all || !acts || !workspace) return fail(MMT_EINVAL, "null pointer argument");
+    if (T <= 0 || B <= 0) return fail(MMT_EINVAL, "bad shape T=%d B=%d", T, B);
+    LstmWs W; int rc = carve_lstm(W, H, workspace);
+    if (rc) return rc;
+    if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(lstm_prep_kernel, dim3(grid_for((size_t)8 * W.HP16 * W.KP)), dim3(256), 0, st, W_rec, W.Wf, W.Wb, H, W.HP16, W.KP, W.KP4);
+    LAUNCH_CHECK("lstm_prep_kernel");
+    const dim3 grid((B + 15) / 16), block(64 * (W.HP16 / 16));
+    const size_t lds = (size_t)2 * 16 * (W.KP + 8) * 2;
+    if (W.HP16 <= 64) hipLaunchKernelGGL((lstm_scan_fwd_kernel<2, 256, true>), grid, block, lds, st, gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, W.KP);
+    else if (W.HP16 <= 128) hipLaunchKernelGGL((lstm_scan_fwd_kernel<4, 512, true>), grid, block, lds, st, gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, W.KP);
+    else hipLaunchKernelGGL((lstm_scan_fwd_kernel<8, 1024, false>), grid, block, lds, st, gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, W.KP);
+    LAUNCH_CHECK("lstm_scan_fwd_kernel");
+    return MMT_OK;
+}
+
+extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, const float* W_rec, const float* c0,
+                                      const float* c_all, const float* acts, float* dgx, float* dh0, float* dc0,
+                                      void* workspace, size_t workspace_bytes, int T, int B, int H, mmt_stream_t stream) {
+    if (!W_rec || !c_all || !acts || !dgx || !workspace) return fail(MMT_EINVAL, "null pointer argument");
+    if (T <= 0 || B <= 0) return fail(MMT_EINVAL, "bad shape T=%d B=%d", T, B);
+    LstmWs W; int rc = carve_lstm(W, H, workspace);
+    if (rc) return rc;
+    if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(lstm_prep_kernel, dim3(grid_for((size_t)8 * W.HP16 * W.KP)), dim3(256), 0, st, W_rec, W.Wf, W.Wb, H, W.HP16, W.KP, W.KP4);
+    LAUNCH_CHECK("lstm_prep_kernel");
+    const dim3 grid((B + 15) / 16), block(64 * (W.HP16 / 16));
+    const size_t lds = (size_t)2 * 16 * (W.KP4 + 8) * 2;
+    static bool attr = false;
+    if (!attr) { if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false>))) return rc; attr = true; }
+    if (W.HP16 <= 64) hipLaunchKernelGGL((lstm_scan_bwd_kernel<8, 256, true>), grid, block, lds, st, dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, W.KP4);
+    else if (W.HP16 <= 128) hipLaunchKernelGGL((lstm_scan_bwd_kernel<16, 512, true>), grid, block, lds, st, dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, W.KP4);
+    else hipLaunchKernelGGL((lstm_scan_bwd_kernel<32, 1024, false>), grid, block, lds, st, dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, W.KP4);
+    LAUNCH_CHECK("lstm_scan_bwd_kernel");
+    return MMT_OK;
+}
+
+// ------------------------------------------------------------------------------------ MFN memory scan
+struct MfnWs { bf16 *WmF, *W2F, *WmB, *W2B; size_t bytes; };
+static void carve_mfn(MfnWs& W, void* base) {
+    Carver c(base);
+    W.WmF = c.take<bf16>(MFN_U * MFN_MD); W.W2F = c.take<bf16>(2 * MFN_MD * MFN_HG);
+    W.WmB = c.take<bf16>(MFN_MD * MFN_U); W.W2B = c.take<bf16>(MFN_U * MFN_MD);
+    W.bytes = c.off;
+}
+extern "C" size_t mmt_mfn_mem_scan_workspace_bytes(void) { MfnWs W; carve_mfn(W, nullptr); return W.bytes; }
+
+static int check_mfn_dims(int mem_dim, int h_gamma) {
+    if (mem_dim != MFN_MD || h_gamma != MFN_HG)
+        return fail(MMT_EUNSUPPORTED, "MFN memory scan is built for mem_dim=%d, gamma hidden=%d (got %d, %d)", MFN_MD, MFN_HG, mem_dim, h_gamma);
+    return MMT_OK;
+}
+
+extern "C" int mmt_mfn_mem_scan_forward(const float* apre, const float* chat, const float* Wm, const float* W2, const float* b2,
+                                        float* mem_all, float* u_all, float* g_all, void* workspace, size_t workspace_bytes,
+                                        int T, int B, int mem_dim, int h_gamma, mmt_stream_t stream) {
+    int rc = check_mfn_dims(mem_dim, h_gamma);
+    if (rc) return rc;
+    if (!apre || !chat || !Wm || !W2 || !b2 || !mem_all || !u_all || !g_all || !workspace) return fail(MMT_EINVAL, "null pointer argument");
+    if (T <= 0 || B <= 0) return fail(MMT_EINVAL, "bad shape T=%d B=%d", T, B);
+    MfnWs W; carve_mfn(W, workspace);
+    if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mfn_prep_kernel, dim3(64), dim3(256), 0, st, Wm, W2, W.WmF, W.W2F, W.WmB, W.W2B);
+    LAUNCH_CHECK("mfn_prep_kernel");
+    hipLaunchKernelGGL(mfn_mem_scan_fwd_kernel, dim3((B + 15) / 16), dim3(512), 0, st, apre, chat, W.WmF, W.W2F, b2, mem_all, u_all, g_all, T, B);
+    LAUNCH_CHECK("mfn_mem_scan_fwd_kernel");
+    return MMT_OK;
+}
+
+extern "C" int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* chat, const float* mem_all, const float* u_all,
+                                         const float* g_all, const float* Wm, const float* W2,
+                                         float* dchat, float* dapre, float* dz_all, void* workspace, size_t workspace_bytes,
+                                         int T, int B, int mem_dim, int h_gamma, mmt_stream_t stream) {
+    int rc = check_mfn_dims(mem_dim, h_gamma);
+    if (rc) return rc;
+    if (!chat || !mem_all || !u_all || !g_all || !Wm || !W2 || !dchat || !dapre || !dz_all || !workspace) return fail(MMT_EINVAL, "null pointer argument");
+    if (T <= 0 || B <= 0) return fail(MMT_EINVAL, "bad shape T=%d B=%d", T, B);
+    MfnWs W; carve_mfn(W, workspace);
+    if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mfn_prep_kernel, dim3(64), dim3(256), 0, st, Wm, W2, W.WmF, W.W2F, W.WmB, W.W2B);
+    LAUNCH_CHECK("mfn_prep_kernel");
+    hipLaunchKernelGGL(mfn_mem_scan_bwd_kernel, dim3((B + 15) / 16), dim3(512), 0, st, dmem_all, chat, mem_all, u_all, g_all, W.WmB, W.W2B,
+                       dchat, dapre, dz_all, T, B);
+    LAUNCH_CHECK("mfn_mem_scan_bwd_kernel");
     return MMT_OK;
 }

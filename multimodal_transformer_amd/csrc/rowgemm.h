@@ -29,7 +29,7 @@ struct RowGemmParams {
     // ---- W operand: bf16 [NP][KP], zero padded; bias fp32 [NP] zero padded ----
     const bf16* W; const float* bias;
     // ---- PLAIN ----
-    int act;                               // 1 = ReLU
+    int act;                               // 1 = ReLU, 2 = tanh, 3 = sigmoid
     const bf16* relu_mask; int ldm;        // multiply by (relu_mask[m][n] > 0)
     const float* residual; int ldr;
     const float* rowscale;                 // multiply row m by rowscale[m]
@@ -216,6 +216,12 @@ __global__ __launch_bounds__(MMT_THREADS) void rowgemm_kernel(const RowGemmParam
                     if (p.act == 1) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                    } else if (p.act == 2) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = 2.0f * __builtin_amdgcn_rcpf(1.0f + fast_exp2(-2.8853900817779268f * v[i])) - 1.0f;
+                    } else if (p.act == 3) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_rcpf(1.0f + fast_exp2(-1.4426950408889634f * v[i]));
                     }
                     if (p.relu_mask) {
                         bf16x4 mk = *reinterpret_cast<const bf16x4*>(p.relu_mask + (size_t)m * p.ldm + n);

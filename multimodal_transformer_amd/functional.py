@@ -162,7 +162,7 @@ class _LinearFn(torch.autograd.Function):
         y = torch.empty(x_.shape[:-1] + (N,), dtype=torch.float32, device=x_.device)
         _lib.check(lib.mmt_linear_forward(_lib.ptr(x_), _lib.ptr(W_), _lib.ptr(b_), _lib.ptr(r_), _lib.ptr(y), _lib.ptr(ws), nbytes,
                                           M, K, N, act, _lib.stream_ptr()))
-        ctx.save_for_backward(x_, W_, y if act == 1 else None, r_)
+        ctx.save_for_backward(x_, W_, y if act != 0 else None, r_)
         ctx.cfg = (M, K, N, act, nbytes, b is not None)
         ctx.ws = ws
         return y
@@ -184,5 +184,128 @@ class _LinearFn(torch.autograd.Function):
 
 
 def linear(x, weight, bias=None, act=0, rowscale=None):
-    """y = act(x W^T + b) [* rowscale per row]; act: 0 none, 1 ReLU."""
+    """y = act(x W^T + b) [* rowscale per row]; act: 0 none, 1 ReLU, 2 tanh, 3 sigmoid."""
     return _LinearFn.apply(x, weight, bias, rowscale, int(act))
+
+
+class _LstmScanFn(torch.autograd.Function):
+    """h_all, c_all = scan(gx, W_rec, h0, c0): the recurrent half of an LSTM layer.
+
+    gx (T,B,4H) already holds x_t W_ih^T + b_ih + b_hh.  Replaces the nn.LSTMCell loop of MFN
+    (transformer/MFT/multiTransformer.py:200-208) and the nn.LSTM step loop of the SFT decoder
+    (transformer/SFT/multiTransformer.py:471-476)."""
+
+    @staticmethod
+    def forward(ctx, gx, W_rec, h0, c0):
+        lib = _lib.load()
+        _lib.require_hip(gx, W_rec, h0, c0)
+        gx_, W_, h0_, c0_ = _f32c(gx), _f32c(W_rec), _f32c(h0), _f32c(c0)
+        T, B, H4 = gx_.shape
+        H = H4 // 4
+        if W_.shape != (4 * H, H):
+            raise ValueError("lstm_scan: W_rec must be (4H,H) = (%d,%d), got %s" % (4 * H, H, tuple(W_.shape)))
+        nbytes = lib.mmt_lstm_scan_workspace_bytes(H)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=gx_.device)
+        h_all = torch.empty(T, B, H, dtype=torch.float32, device=gx_.device)
+        c_all = torch.empty_like(h_all)
+        acts = torch.empty(T, B, 4 * H, dtype=torch.float32, device=gx_.device)
+        _lib.check(lib.mmt_lstm_scan_forward(_lib.ptr(gx_), _lib.ptr(W_), _lib.ptr(h0_), _lib.ptr(c0_), _lib.ptr(h_all), _lib.ptr(c_all),
+                                             _lib.ptr(acts), _lib.ptr(ws), nbytes, T, B, H, _lib.stream_ptr()))
+        ctx.save_for_backward(W_, h0_, c0_, h_all, c_all, acts)
+        ctx.dims = (T, B, H, nbytes)
+        return h_all, c_all
+
+    @staticmethod
+    def backward(ctx, dh_all, dc_all):
+        lib = _lib.load()
+        W_, h0_, c0_, h_all, c_all, acts = ctx.saved_tensors
+        T, B, H, nbytes = ctx.dims
+        dev = h_all.device
+        dh_, dc_ = _f32c(dh_all), _f32c(dc_all)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        dgx = torch.empty(T, B, 4 * H, dtype=torch.float32, device=dev)
+        dh0 = torch.empty(B, H, dtype=torch.float32, device=dev)
+        dc0 = torch.empty(B, H, dtype=torch.float32, device=dev)
+        _lib.check(lib.mmt_lstm_scan_backward(_lib.ptr(dh_), _lib.ptr(dc_), _lib.ptr(W_), _lib.ptr(c0_), _lib.ptr(c_all), _lib.ptr(acts),
+                                              _lib.ptr(dgx), _lib.ptr(dh0), _lib.ptr(dc0), _lib.ptr(ws), nbytes, T, B, H, _lib.stream_ptr()))
+        dW = None
+        if ctx.needs_input_grad[1]:
+            # dW_rec = sum_{t,b} dG[t,b,:]^T h_{t-1}[b,:]  — a window-contraction: the weight-gradient GEMM
+            first = h0_.unsqueeze(0) if h0_ is not None else torch.zeros(1, B, H, dtype=torch.float32, device=dev)
+            hprev = torch.cat([first, h_all[:-1]], dim=0)
+            M = T * B
+            lb = lib.mmt_linear_workspace_bytes(M, H, 4 * H)
+            lws = torch.zeros(lb, dtype=torch.uint8, device=dev)
+            dW = torch.empty_like(W_)
+            _lib.check(lib.mmt_linear_backward(_lib.ptr(dgx), _lib.ptr(hprev), _lib.ptr(W_), None, None, None, _lib.ptr(dW), None,
+                                               _lib.ptr(lws), lb, M, H, 4 * H, 0, _lib.stream_ptr()))
+        return (dgx, dW, dh0 if (h0_ is not None and ctx.needs_input_grad[2]) else None,
+                dc0 if (c0_ is not None and ctx.needs_input_grad[3]) else None)
+
+
+def lstm_scan(gx, W_rec, h0=None, c0=None):
+    return _LstmScanFn.apply(gx, W_rec, h0, c0)
+
+
+class _MfnMemScanFn(torch.autograd.Function):
+    """mem_all = scan(apre, chat, Wm, W2, b2): the MFN memory recurrence
+    (transformer/MFT/multiTransformer.py:221-224) with everything that does not depend on mem batched before."""
+
+    @staticmethod
+    def forward(ctx, apre, chat, Wm, W2, b2):
+        lib = _lib.load()
+        _lib.require_hip(apre, chat, Wm, W2, b2)
+        a_, c_, Wm_, W2_, b2_ = _f32c(apre), _f32c(chat), _f32c(Wm), _f32c(W2), _f32c(b2)
+        T, B, U = a_.shape
+        MD, HG = c_.shape[-1], W2_.shape[-1]
+        if U != 2 * HG or Wm_.shape != (U, MD) or W2_.shape != (2, MD, HG) or b2_.shape != (2, MD):
+            raise ValueError("mfn_mem_scan: inconsistent shapes")
+        dev = a_.device
+        nbytes = lib.mmt_mfn_mem_scan_workspace_bytes()
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        mem_all = torch.empty(T, B, MD, dtype=torch.float32, device=dev)
+        u_all = torch.empty(T, B, U, dtype=torch.float32, device=dev)
+        g_all = torch.empty(T, B, 2 * MD, dtype=torch.float32, device=dev)
+        _lib.check(lib.mmt_mfn_mem_scan_forward(_lib.ptr(a_), _lib.ptr(c_), _lib.ptr(Wm_), _lib.ptr(W2_), _lib.ptr(b2_), _lib.ptr(mem_all),
+                                                _lib.ptr(u_all), _lib.ptr(g_all), _lib.ptr(ws), nbytes, T, B, MD, HG, _lib.stream_ptr()))
+        ctx.save_for_backward(c_, Wm_, W2_, mem_all, u_all, g_all)
+        ctx.dims = (T, B, U, MD, HG, nbytes)
+        return mem_all
+
+    @staticmethod
+    def backward(ctx, dmem):
+        lib = _lib.load()
+        c_, Wm_, W2_, mem_all, u_all, g_all = ctx.saved_tensors
+        T, B, U, MD, HG, nbytes = ctx.dims
+        dev = c_.device
+        dm = _f32c(dmem)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dchat = torch.empty_like(c_)
+        dapre = torch.empty_like(u_all)
+        dz = torch.empty_like(g_all)
+        _lib.check(lib.mmt_mfn_mem_scan_backward(_lib.ptr(dm), _lib.ptr(c_), _lib.ptr(mem_all), _lib.ptr(u_all), _lib.ptr(g_all), _lib.ptr(Wm_),
+                                                 _lib.ptr(W2_), _lib.ptr(dchat), _lib.ptr(dapre), _lib.ptr(dz), _lib.ptr(ws), nbytes,
+                                                 T, B, MD, HG, _lib.stream_ptr()))
+        M = T * B
+        st = _lib.stream_ptr()
+        # batched weight gradients (window contractions): dWm = dapre^T mem_prev ; dW2_g = dz_g^T u_g ; db2 = sum dz
+        mem_prev = torch.cat([torch.zeros(1, B, MD, dtype=torch.float32, device=dev), mem_all[:-1]], dim=0)
+        dWm = torch.empty_like(Wm_)
+        lb = lib.mmt_linear_workspace_bytes(M, MD, U)
+        lws = torch.zeros(lb, dtype=torch.uint8, device=dev)
+        _lib.check(lib.mmt_linear_backward(_lib.ptr(dapre), _lib.ptr(mem_prev), _lib.ptr(Wm_), None, None, None, _lib.ptr(dWm), None,
+                                           _lib.ptr(lws), lb, M, MD, U, 0, st))
+        dW2 = torch.empty_like(W2_)
+        db2 = torch.empty(2, MD, dtype=torch.float32, device=dev)
+        lb2 = lib.mmt_linear_workspace_bytes(M, HG, MD)
+        for g in range(2):
+            dzg = dz[..., g * MD:(g + 1) * MD].contiguous()
+            ug = u_all[..., g * HG:(g + 1) * HG].contiguous()
+            lws2 = torch.zeros(lb2, dtype=torch.uint8, device=dev)
+            _lib.check(lib.mmt_linear_backward(_lib.ptr(dzg), _lib.ptr(ug), _lib.ptr(W2_[g]), None, None, None, _lib.ptr(dW2[g]),
+                                               _lib.ptr(db2[g]), _lib.ptr(lws2), lb2, M, HG, MD, 0, st))
+        return dapre, dchat, dWm, dW2, db2
+
+
+def mfn_mem_scan(apre, chat, Wm, W2, b2):
+    return _MfnMemScanFn.apply(apre, chat, Wm, W2, b2)

@@ -192,3 +192,203 @@ class Encoder(nn.Module):
         seed = (torch.initial_seed() * 1000003 + self._seed_counter) & 0x7FFFFFFFFFFFFFFF if p > 0.0 else 0
         return F_hip.encoder_stack(x, mask, flat, l0.self_attn.h, l0.feed_forward.w_1.weight.shape[0], len(self.layers),
                                    eps=self.norm.eps, dropout_p=p, seed=seed)
+
+
+def _encoder(embed_dim, h, d_ff, dropout, N):
+    return Encoder(EncoderLayer(embed_dim, MultiHeadedAttention(h, embed_dim), PositionwiseFeedForward(embed_dim, d_ff, dropout),
+                                dropout), N)
+
+
+class MFN(nn.Module):
+    """Memory Fusion Network gate (transformer/MFT/multiTransformer.py:118-248).
+
+    inputs: {mod: (T,B,dims[mod])} -> (B,T,output_dim).  The reference walks T steps of ~40 small ops; here
+    only the two true recurrences run as scans (per-modality LSTM state, and the memory update) and
+    everything that depends only on the inputs or on the LSTM cell states is batched over all T windows
+    through the row GEMM:
+        A  gx_mod = x W_ih^T + b              -> LSTM scan             (:207-208)
+        B  att1 / att2 MLPs on cStar, and the `attended` part of both gamma fc1 layers   (:218-223)
+        C  memory scan                        (:221-224)
+        D  read-out MLP                       (:238-247)
+    """
+    hidden_dim = {"linguistic": 88, "emotient": 16, "acoustic": 48, "image": 88}
+
+    def __init__(self, mods, dims, output_dim, device=torch.device("cuda:0")):
+        super().__init__()
+        self.mods = list(mods)
+        self.dims = dims
+        total_h = sum(self.hidden_dim[m] for m in self.mods)
+        self.mem_dim = 128
+        att_in = 2 * total_h
+        gamma_in = att_in + self.mem_dim
+        self.lstm = {}
+        for mod in self.mods:
+            self.lstm[mod] = nn.LSTMCell(dims[mod], self.hidden_dim[mod])
+            self.add_module("lstm_%s" % mod, self.lstm[mod])
+        self.att1_fc1 = nn.Linear(att_in, 128)
+        self.att1_fc2 = nn.Linear(128, att_in)
+        self.att1_dropout = nn.Dropout(0.0)
+        self.att2_fc1 = nn.Linear(att_in, 256)
+        self.att2_fc2 = nn.Linear(256, self.mem_dim)
+        self.att2_dropout = nn.Dropout(0.0)
+        self.gamma1_fc1 = nn.Linear(gamma_in, 64)
+        self.gamma1_fc2 = nn.Linear(64, self.mem_dim)
+        self.gamma1_dropout = nn.Dropout(0.2)
+        self.gamma2_fc1 = nn.Linear(gamma_in, 64)
+        self.gamma2_fc2 = nn.Linear(64, self.mem_dim)
+        self.gamma2_dropout = nn.Dropout(0.2)
+        self.out_fc1 = nn.Linear(total_h + self.mem_dim, 64)
+        self.out_fc2 = nn.Linear(64, output_dim)
+        self.out_dropout = nn.Dropout(0.5)
+        self.device = _hip_device(device)
+        self.to(self.device)
+
+    def forward(self, inputs):
+        if self.training and (self.gamma1_dropout.p > 0 or self.out_dropout.p > 0):
+            raise NotImplementedError("MFN: train-mode dropout is not implemented yet; call .eval()")
+        hs, c_prev, c_new = [], [], []
+        for mod in self.mods:
+            cell = self.lstm[mod]
+            x = inputs[mod]                                           # (T,B,d), possibly a permuted view
+            gx = F_hip.linear(x, cell.weight_ih, cell.bias_ih + cell.bias_hh)
+            h_all, c_all = F_hip.lstm_scan(gx, cell.weight_hh)
+            hs.append(h_all)
+            c_new.append(c_all)
+            c_prev.append(torch.cat([torch.zeros_like(c_all[:1]), c_all[:-1]], dim=0))
+        c_star = torch.cat(c_prev + c_new, dim=-1)                    # (T,B,2*sumH)   :215-217
+        A = c_star.shape[-1]
+        att = torch.softmax(F_hip.linear(F_hip.linear(c_star, self.att1_fc1.weight, self.att1_fc1.bias, act=1),
+                                         self.att1_fc2.weight, self.att1_fc2.bias), dim=-1)
+        attended = att * c_star
+        c_hat = F_hip.linear(F_hip.linear(attended, self.att2_fc1.weight, self.att2_fc1.bias, act=1),
+                             self.att2_fc2.weight, self.att2_fc2.bias, act=2)
+        w1 = torch.cat([self.gamma1_fc1.weight, self.gamma2_fc1.weight], dim=0)          # (128, A+mem)
+        apre = F_hip.linear(attended, w1[:, :A], torch.cat([self.gamma1_fc1.bias, self.gamma2_fc1.bias]))
+        mem_all = F_hip.mfn_mem_scan(apre, c_hat, w1[:, A:],
+                                     torch.stack([self.gamma1_fc2.weight, self.gamma2_fc2.weight]),
+                                     torch.stack([self.gamma1_fc2.bias, self.gamma2_fc2.bias]))
+        last = torch.cat(hs + [mem_all], dim=-1)
+        out = F_hip.linear(F_hip.linear(last, self.out_fc1.weight, self.out_fc1.bias, act=1), self.out_fc2.weight, self.out_fc2.bias)
+        return out.permute(1, 0, 2)
+
+
+class MultiTransformer(nn.Module):
+    """MFT sequence model (transformer/MFT/multiTransformer.py:250-313): per-modality Linear embed ->
+    own Encoder stack -> MFN gate -> mask.  ``attn{mod}`` / ``ff{mod}`` are registered as in the reference
+    (:273-276) although only deep copies of them are used (:277): they are dead parameters kept so that
+    reference checkpoints load with identical keys."""
+
+    def __init__(self, mods, window_embed_size, N=6, d_ff=128, h=8, dropout=0.1, n_layers=1, device=torch.device("cuda:0"),
+                 embed_dim=None):
+        super().__init__()
+        self.mods = list(mods)
+        self.window_embed_size = window_embed_size
+        self.embed_dim = embed_dim or {"linguistic": 256, "emotient": 16, "acoustic": 256, "image": 256}
+        self.embed, self.transformer, self.attn, self.ff = {}, {}, {}, {}
+        for mod in self.mods:
+            e = self.embed_dim[mod]
+            self.embed[mod] = nn.Linear(window_embed_size[mod], e)
+            self.add_module("embed_%s" % mod, self.embed[mod])
+            self.attn[mod] = MultiHeadedAttention(h, e)
+            self.ff[mod] = PositionwiseFeedForward(e, d_ff, dropout)
+            self.add_module("attn%s" % mod, self.attn[mod])
+            self.add_module("ff%s" % mod, self.ff[mod])
+            self.transformer[mod] = Encoder(EncoderLayer(e, copy.deepcopy(self.attn[mod]), copy.deepcopy(self.ff[mod]), dropout), N)
+            self.add_module("transformer_%s" % mod, self.transformer[mod])
+        self.mfn = MFN(self.mods, self.embed_dim, 1, device=device)
+        self.device = _hip_device(device)
+        self.to(self.device)
+
+    def forward(self, inputs, mask, lengths, tgt_init=0.5, target=None):
+        gate_in = {}
+        for mod in self.mods:
+            e = F_hip.linear(inputs[mod], self.embed[mod].weight, self.embed[mod].bias)
+            e = self.transformer[mod](e, mask)
+            gate_in[mod] = e.permute(1, 0, 2)
+        return self.mfn(gate_in) * mask.float()
+
+
+class _DecoderMixin:
+    """Autoregressive 1-layer LSTM decoder + MLP shared by UniTransformer and NLPTransformer
+    (transformer/SFT/multiTransformer.py:463-483).  Step t feeds [o_{t-1}; enc_t] with o = h, so
+        gates_t = enc_t W_ih[:, d:]^T + b  +  h_{t-1} (W_ih[:, :d] + W_hh)^T          for t >= 1
+        gates_0 = enc_0 W_ih[:, d:]^T + b  +  h0 W_hh^T                               (o_{-1} = 0, h_{-1} = dec_h0)
+    i.e. one batched input projection plus one LSTM scan with W_rec = W_ih[:, :d] + W_hh."""
+
+    def _decode(self, enc, mask):
+        B, T, d = enc.shape
+        if self.decoder.num_layers != 1:
+            raise NotImplementedError("only the reference's single-layer decoder is supported")
+        W_ih, W_hh = self.decoder.weight_ih_l0, self.decoder.weight_hh_l0
+        bias = self.decoder.bias_ih_l0 + self.decoder.bias_hh_l0
+        gx = F_hip.linear(enc.transpose(0, 1), W_ih[:, d:], bias)                           # (T,B,4d)
+        first = F_hip.linear(self.dec_h0[0], W_hh)                                          # (1,4d): h0 W_hh^T
+        gx = torch.cat([gx[:1] + first.unsqueeze(0), gx[1:]], dim=0)
+        c0 = self.dec_c0[0].expand(B, d)
+        h_all, _ = F_hip.lstm_scan(gx, W_ih[:, :d] + W_hh, None, c0)
+        o = h_all.transpose(0, 1)                                                           # (B,T,d)
+        hid = F_hip.linear(o, self.out[0].weight, self.out[0].bias, act=1)
+        return F_hip.linear(hid, self.out[2].weight, self.out[2].bias, rowscale=mask.float().reshape(-1))
+
+
+class UniTransformer(nn.Module, _DecoderMixin):
+    """Single-modality model (transformer/MFT/multiTransformer.py:315-376): Linear embed -> Encoder -> LSTM decoder -> MLP."""
+
+    def __init__(self, window_embed_size, embed_dim=256, h_dim=128, N=6, d_ff=128, h=8, dropout=0.1, n_layers=1,
+                 device=torch.device("cuda:0")):
+        super().__init__()
+        self.embed_dim, self.h_dim = embed_dim, h_dim
+        self.embed = nn.Linear(window_embed_size, embed_dim)
+        self.encoder = _encoder(embed_dim, h, d_ff, dropout, N)
+        self.decoder = nn.LSTM(2 * embed_dim, embed_dim, n_layers, batch_first=True)
+        self.dec_h0 = nn.Parameter(torch.zeros(n_layers, 1, embed_dim))
+        self.dec_c0 = nn.Parameter(torch.zeros(n_layers, 1, embed_dim))
+        self.out = nn.Sequential(nn.Linear(embed_dim, h_dim), nn.ReLU(), nn.Linear(h_dim, 1))
+        self.device = _hip_device(device)
+        self.to(self.device)
+
+    def forward(self, inputs, mask, lengths, tgt_init=0.5, target=None):
+        e = F_hip.linear(inputs, self.embed.weight, self.embed.bias)
+        return self._decode(self.encoder(e, mask), mask)
+
+
+class UniFullTransformer(nn.Module):
+    """B2-Trans model (transformer/B2-Trans/multiTransformer.py:378-420): Linear embed -> Encoder -> MLP -> mask."""
+
+    def __init__(self, window_embed_size, embed_dim=256, h_dim=128, N=6, d_ff=128, h=8, dropout=0.1, n_layers=1,
+                 device=torch.device("cuda:0")):
+        super().__init__()
+        self.embed_dim, self.h_dim = embed_dim, h_dim
+        self.embed = nn.Linear(window_embed_size, embed_dim)
+        self.encoder = _encoder(embed_dim, h, d_ff, dropout, N)
+        self.out = nn.Sequential(nn.Linear(embed_dim, h_dim), nn.ReLU(), nn.Linear(h_dim, 1))
+        self.device = _hip_device(device)
+        self.to(self.device)
+
+    def forward(self, inputs, mask, lengths, tgt_init=0.5, target=None):
+        enc = self.encoder(F_hip.linear(inputs, self.embed.weight, self.embed.bias), mask)
+        hid = F_hip.linear(enc, self.out[0].weight, self.out[0].bias, act=1)
+        return F_hip.linear(hid, self.out[2].weight, self.out[2].bias, rowscale=mask.float().reshape(-1))
+
+
+class NLPTransformer(nn.Module, _DecoderMixin):
+    """SFT model (transformer/SFT/multiTransformer.py:422-484): Dropout(0.1) -> Linear -> ReLU embed,
+    Encoder, LSTM decoder, MLP, mask."""
+
+    def __init__(self, window_embed_size, embed_dim=256, h_dim=128, N=6, d_ff=128, h=8, dropout=0.1, n_layers=1,
+                 device=torch.device("cuda:0")):
+        super().__init__()
+        self.embed_dim, self.h_dim = embed_dim, h_dim
+        self.embed = nn.Sequential(nn.Dropout(0.1), nn.Linear(window_embed_size, embed_dim), nn.ReLU())
+        self.encoder = _encoder(embed_dim, h, d_ff, dropout, N)
+        self.decoder = nn.LSTM(2 * embed_dim, embed_dim, n_layers, batch_first=True)
+        self.dec_h0 = nn.Parameter(torch.zeros(n_layers, 1, embed_dim))
+        self.dec_c0 = nn.Parameter(torch.zeros(n_layers, 1, embed_dim))
+        self.out = nn.Sequential(nn.Linear(embed_dim, h_dim), nn.ReLU(), nn.Linear(h_dim, 1))
+        self.device = _hip_device(device)
+        self.to(self.device)
+
+    def forward(self, inputs, mask, lengths, tgt_init=0.5, target=None):
+        x = self.embed[0](inputs)                       # nn.Dropout: identity in eval mode (train: torch's generator)
+        e = F_hip.linear(x, self.embed[1].weight, self.embed[1].bias, act=1)
+        return self._decode(self.encoder(e, mask), mask)

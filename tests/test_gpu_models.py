@@ -1,0 +1,195 @@
+"""GPU parity tests for the T-sequential scans and the sequence models (HIP path vs oracle / golden).
+
+Tolerances as in test_gpu_parity.py (bf16 MFMA operands, fp32 state): outputs within OUT_RTOL relative-L2,
+gradients within GRAD_RTOL (RELU_GRAD_RTOL where a ReLU lies on the path), valence CCC >= 1 - 1e-3, and the
+mask product exact (outputs are exactly 0 where mask == 0).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import recipe as R
+from conftest import load_golden, rel_l2, grad_close
+from test_gpu_parity import OUT_RTOL, GRAD_RTOL, RELU_GRAD_RTOL, CCC_MIN, _report, mta
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _oracle_lstm(gx, W, h0, c0):
+    T, B, H4 = gx.shape
+    H = H4 // 4
+    h = h0 if h0 is not None else torch.zeros(B, H, dtype=gx.dtype)
+    c = c0 if c0 is not None else torch.zeros(B, H, dtype=gx.dtype)
+    eye = torch.eye(4 * H, dtype=gx.dtype)
+    zb = torch.zeros(4 * H, dtype=gx.dtype)
+    hs, cs = [], []
+    for t in range(T):
+        # the oracle's cell with the pre-projected gx[t] as its input and an identity input weight
+        h, c = oracle.lstm_cell(gx[t], h, c, eye, W, zb, zb)
+        hs.append(h)
+        cs.append(c)
+    return torch.stack(hs), torch.stack(cs)
+
+
+@pytest.mark.parametrize("T,B,H,init", [(20, 3, 88, False), (7, 17, 48, False), (50, 4, 128, True), (12, 33, 40, True),
+                                        (1, 1, 16, False), (9, 5, 256, True)])
+def test_lstm_scan(dev, T, B, H, init):
+    tag = "lstm%d_%d_%d" % (T, B, H)
+    gx = R.gen_normal(tag + "gx", (T, B, 4 * H), 13)
+    W = R.gen_normal(tag + "w", (4 * H, H), 13) / np.sqrt(H)
+    h0 = 0.5 * R.gen_normal(tag + "h0", (B, H), 13) if init else None
+    c0 = 0.5 * R.gen_normal(tag + "c0", (B, H), 13) if init else None
+    gh, gc = R.gen_normal(tag + "gh", (T, B, H), 13), R.gen_normal(tag + "gc", (T, B, H), 13)
+    leaves = [t.double().requires_grad_() if t is not None else None for t in (gx, W, h0, c0)]
+    rh, rc = _oracle_lstm(*leaves)
+    ((rh * gh.double()).sum() + (rc * gc.double()).sum()).backward()
+    F = mta().functional
+    gl = [t.to(dev).requires_grad_() if t is not None else None for t in (gx, W, h0, c0)]
+    h_all, c_all = F.lstm_scan(*gl)
+    ((h_all * gh.to(dev)).sum() + (c_all * gc.to(dev)).sum()).backward()
+    assert _report(tag + " h", h_all.detach().cpu(), rh.detach()) < OUT_RTOL
+    assert _report(tag + " c", c_all.detach().cpu(), rc.detach()) < OUT_RTOL
+    for name, a, b in zip(("dgx", "dW", "dh0", "dc0"), gl, leaves):
+        if a is not None:
+            assert _report(tag + " " + name, a.grad.cpu(), b.grad) < GRAD_RTOL, name
+
+
+def _oracle_mem_scan(apre, chat, Wm, W2, b2):
+    T, B, U = apre.shape
+    MD, HG = chat.shape[-1], W2.shape[-1]
+    mem = torch.zeros(B, MD, dtype=apre.dtype)
+    out = []
+    for t in range(T):
+        u = torch.relu(apre[t] + mem @ Wm.t())
+        g1 = torch.sigmoid(u[:, :HG] @ W2[0].t() + b2[0])
+        g2 = torch.sigmoid(u[:, HG:] @ W2[1].t() + b2[1])
+        mem = g1 * mem + g2 * chat[t]
+        out.append(mem)
+    return torch.stack(out)
+
+
+@pytest.mark.parametrize("T,B", [(20, 3), (1, 1), (33, 18)])
+def test_mfn_mem_scan(dev, T, B):
+    tag = "mem%d_%d" % (T, B)
+    apre = R.gen_normal(tag + "a", (T, B, 128), 17)
+    chat = torch.tanh(R.gen_normal(tag + "c", (T, B, 128), 17))
+    Wm = R.gen_normal(tag + "wm", (128, 128), 17) / np.sqrt(128)
+    W2 = R.gen_normal(tag + "w2", (2, 128, 64), 17) / 8
+    b2 = 0.1 * R.gen_normal(tag + "b2", (2, 128), 17)
+    g = R.gen_normal(tag + "g", (T, B, 128), 17)
+    leaves = [t.double().requires_grad_() for t in (apre, chat, Wm, W2, b2)]
+    ref = _oracle_mem_scan(*leaves)
+    (ref * g.double()).sum().backward()
+    gl = [t.to(dev).requires_grad_() for t in (apre, chat, Wm, W2, b2)]
+    out = mta().functional.mfn_mem_scan(*gl)
+    (out * g.to(dev)).sum().backward()
+    assert _report(tag + " mem", out.detach().cpu(), ref.detach()) < OUT_RTOL
+    for name, a, b in zip(("dapre", "dchat", "dWm", "dW2", "db2"), gl, leaves):
+        assert _report(tag + " " + name, a.grad.cpu(), b.grad) < RELU_GRAD_RTOL, name
+
+
+def _load_into(module, seed=R.SEED):
+    p32 = R.gen_params(R.shapes_of(module.state_dict()), seed)
+    module.load_state_dict(p32)
+    return p32
+
+
+def test_mfn_gate_golden(dev):
+    fx = load_golden("mfn_avl")
+    MT = mta().multiTransformer
+    mods = R.MODS_AVL
+    mfn = MT.MFN(mods, {m: 256 for m in mods}, 1, device=dev)
+    p32 = _load_into(mfn)
+    assert abs(R.weights_checksum(p32) - float(fx["checksum"])) <= 1e-6 * float(fx["checksum"])
+    mfn = mfn.to(dev).eval()
+    ins = {m: R.gen_normal("mfn:" + m, (20, 3, 256), R.SEED).to(dev).requires_grad_() for m in mods}
+    g = R.gen_normal("mfn:g", (3, 20, 1), R.SEED).to(dev)
+    y = mfn(ins)
+    (y * g).sum().backward()
+    assert y.shape == (3, 20, 1)
+    assert _report("mfn out", y.detach().cpu(), fx["out"]) < OUT_RTOL
+    for m in mods:
+        assert _report("mfn dx:" + m, ins[m].grad.cpu(), fx["dx:" + m]) < RELU_GRAD_RTOL
+    scale = max(float(np.abs(fx[k]).max()) for k in fx if k.startswith("grad:"))
+    for n, p in mfn.named_parameters():
+        got, ref = p.grad.cpu().numpy(), fx["grad:" + n]
+        if not grad_close(got, ref, RELU_GRAD_RTOL, 3e-3 * scale):
+            _report("mfn FAIL d" + n, got, ref)
+        assert grad_close(got, ref, RELU_GRAD_RTOL, 3e-3 * scale), n
+
+
+def _check_model(dev, fx, model, out_fn, name, lengths, T):
+    mask = R.prefix_mask(lengths, T)
+    target = (R.gen_uniform(name + ":target", (len(lengths), T, 1), R.SEED) * mask).to(dev)
+    out = out_fn(mask.to(dev))
+    loss = ((out - target) ** 2).sum() / float(sum(lengths))
+    loss.backward()
+    o = out.detach().cpu().numpy()
+    assert o.shape == fx["out"].shape
+    r = _report(name + " valence", o, fx["out"])
+    ccc = mta().eval_ccc(fx["out"], o)
+    print("%-44s CCC %.6f   loss %.6f (ref %.6f)" % (name, ccc, loss.item(), float(fx["loss"])))
+    assert r < OUT_RTOL and ccc >= CCC_MIN
+    assert (o[mask.numpy() == 0] == 0).all()                       # exact zeros where mask == 0
+    assert abs(loss.item() - float(fx["loss"])) < 2e-2 * max(abs(float(fx["loss"])), 1e-3)
+    worst = 0.0
+    # absolute floor for analytically-zero gradients (key-projection bias: softmax is shift invariant)
+    floor = 1e-3 * max(float(fx[k]) for k in fx if k.startswith("gnorm:"))
+    for n, p in model.named_parameters():
+        ref = float(fx["gnorm:" + n])
+        if ref < 0:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, n     # dead parameters of the reference
+            continue
+        assert p.grad is not None, n
+        got = float(p.grad.double().pow(2).sum().sqrt())
+        if ref > floor:
+            worst = max(worst, abs(got - ref) / ref)
+        assert abs(got - ref) <= RELU_GRAD_RTOL * ref + floor, (n, got, ref)
+    print("%-44s worst |grad-norm| deviation %.3e" % (name, worst))
+    for k in fx:
+        if k.startswith("grad:"):
+            got = dict(model.named_parameters())[k[5:]].grad.cpu().numpy()
+            assert _report(name + " d" + k[5:], got, fx[k]) < RELU_GRAD_RTOL, k
+
+
+@pytest.mark.parametrize("name,kw", [("model_sft_d128", dict(embed_dim=128, h=8)), ("model_sft_d40", dict(embed_dim=40, h=4)),
+                                     ("model_sft_default", dict())])
+def test_nlp_transformer_golden(dev, name, kw):
+    fx = load_golden(name)
+    MT = mta().multiTransformer
+    model = MT.NLPTransformer(512, device=dev, **kw)
+    _load_into(model)
+    model = model.to(dev).eval()
+    lengths = list(fx["lengths"])
+    x = torch.tanh(R.gen_normal(name + ":x", (4, 50, 512), R.SEED)).to(dev)
+    _check_model(dev, fx, model, lambda mask: model(x, mask, lengths), name, lengths, 50)
+
+
+def test_uni_full_transformer_golden(dev):
+    fx = load_golden("model_b2_text")
+    MT = mta().multiTransformer
+    model = MT.UniFullTransformer(300, device=dev)
+    _load_into(model)
+    model = model.to(dev).eval()
+    lengths = list(fx["lengths"])
+    x = R.gen_normal("model_b2:x", (4, 50, 300), R.SEED).to(dev)
+    _check_model(dev, fx, model, lambda mask: model(x, mask, lengths), "model_b2_text", lengths, 50)
+
+
+def test_multi_transformer_golden(dev):
+    fx = load_golden("model_mft_avl")
+    MT = mta().multiTransformer
+    mods = R.MODS_AVL
+    model = MT.MultiTransformer(mods, R.EMBED_AVL, device=dev)
+    _load_into(model)
+    model = model.to(dev).eval()
+    lengths = list(fx["lengths"])
+    ins = {m: R.gen_normal("model_mft:" + m, (4, 50, R.EMBED_AVL[m]), R.SEED).to(dev) for m in mods}
+    _check_model(dev, fx, model, lambda mask: model(ins, mask, lengths), "model_mft_avl", lengths, 50)
