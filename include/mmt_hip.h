@@ -126,16 +126,25 @@ int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, const float
  * apre (T,B,128): gamma{1,2}_fc1 applied to the `attended` part of `both` (+bias), rows [gamma1(64); gamma2(64)];
  * Wm (128,128): the memory columns of gamma{1,2}_fc1.weight stacked the same way; W2 (2,128,64), b2 (2,128):
  * gamma{1,2}_fc2; chat (T,B,128) = cHat.  Outputs mem_all (T,B,128) and u_all (T,B,128), g_all (T,B,256) kept
- * for the backward.  mem_dim must be 128 and h_gamma 64 (the reference's constants, :133,140-141). */
+ * for the backward.  mem_dim must be 128 and h_gamma 64 (the reference's constants, :133,140-141).
+ * dropout_p / seed: gamma{1,2}_dropout on relu(fc1) in train mode (0 = eval). */
 size_t mmt_mfn_mem_scan_workspace_bytes(void);
 int mmt_mfn_mem_scan_forward(const float* apre, const float* chat, const float* Wm, const float* W2, const float* b2,
                              float* mem_all, float* u_all, float* g_all, void* workspace, size_t workspace_bytes,
-                             int T, int B, int mem_dim, int h_gamma, mmt_stream_t stream);
+                             int T, int B, int mem_dim, int h_gamma, float dropout_p, uint64_t seed, mmt_stream_t stream);
 /* dmem_all (T,B,128) or NULL -> dchat (T,B,128), dapre (T,B,128), dz_all (T,B,256) (pre-sigmoid gate gradients). */
 int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* chat, const float* mem_all, const float* u_all,
                               const float* g_all, const float* Wm, const float* W2,
                               float* dchat, float* dapre, float* dz_all, void* workspace, size_t workspace_bytes,
-                              int T, int B, int mem_dim, int h_gamma, mmt_stream_t stream);
+                              int T, int B, int mem_dim, int h_gamma, float dropout_p, mmt_stream_t stream);
+
+/* ---- Test hook: the keep-mask (1 = kept) of dropout stream `stream_id` for indices [0,n) under (p, seed), and the
+ * scale applied to kept values (host pointer, may be NULL).  Streams used by the encoder stack for layer l:
+ * 4l+0 attention probabilities, index ((b*h+head)*Tp + q)*Tp + key (Tp = T rounded up to 32);
+ * 4l+1 / 4l+3 sublayer outputs and 4l+2 FFN hidden, index m*NP + n (NP = width rounded up to 64);
+ * 1000: MFN gamma hidden, index (t*B+b)*128 + j. */
+int mmt_debug_dropout_mask(float p, uint64_t seed, uint32_t stream_id, uint64_t n, uint8_t* keep, float* host_scale_out,
+                           mmt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -187,29 +187,31 @@ static int launch_rowgemm(const RowGemmParams& p, hipStream_t st, int site = S_O
     return MMT_OK;
 }
 
-static RowGemmParams rg_zero() { RowGemmParams p; memset(&p, 0, sizeof(p)); return p; }
+static RowGemmParams rg_zero() { RowGemmParams p; memset(&p, 0, sizeof(p)); p.mask_scale = 1.0f; return p; }
+
+static DropCfg no_drop() { return make_drop(0.f, 0, 0); }
 
 static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* VT, bf16* ctx, bf16* ctxT, float* lse,
-                           const EncDims& D, hipStream_t st) {
+                           const EncDims& D, hipStream_t st, DropCfg drop = no_drop()) {
     dim3 grid((D.nt + 3) / 4, D.B * D.h);
     ProfScope prof(S_ATTN_FWD, st);
-    if (DKP == 16) hipLaunchKernelGGL((attn_fwd_kernel<16>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, D.h, D.T, D.nt, D.L.HDP, D.MP);
-    else hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, D.h, D.T, D.nt, D.L.HDP, D.MP);
+    if (DKP == 16) hipLaunchKernelGGL((attn_fwd_kernel<16>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, D.h, D.T, D.nt, D.L.HDP, D.MP, drop);
+    else hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, D.h, D.T, D.nt, D.L.HDP, D.MP, drop);
     LAUNCH_CHECK("attn_fwd_kernel");
     return MMT_OK;
 }
 
 static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* KR, const bf16* KT_, const bf16* VR,
                            const bf16* dOR, const bf16* dOT, const float* lse, const float* delta, float* dqslab,
-                           bf16* dkv, bf16* dkvT, const EncDims& D, hipStream_t st) {
+                           bf16* dkv, bf16* dkvT, const EncDims& D, hipStream_t st, DropCfg drop = no_drop()) {
     dim3 grid(D.nkb, D.B * D.h);
     ProfScope prof(S_ATTN_BWD, st);
     if (DKP == 16)
         hipLaunchKernelGGL((attn_bwd_kernel<16, KT_BWD>), grid, dim3(MMT_THREADS), 0, st, QR, QT, KR, KT_, VR, dOR, dOT, lse, delta,
-                           dqslab, dkv, D.L.NQ, dkvT, D.MP, D.h, D.T, D.nt, D.M, D.L.HDP);
+                           dqslab, dkv, D.L.NQ, dkvT, D.MP, D.h, D.T, D.nt, D.M, D.L.HDP, drop);
     else
         hipLaunchKernelGGL((attn_bwd_kernel<32, KT_BWD>), grid, dim3(MMT_THREADS), 0, st, QR, QT, KR, KT_, VR, dOR, dOT, lse, delta,
-                           dqslab, dkv, D.L.NQ, dkvT, D.MP, D.h, D.T, D.nt, D.M, D.L.HDP);
+                           dqslab, dkv, D.L.NQ, dkvT, D.MP, D.h, D.T, D.nt, D.M, D.L.HDP, drop);
     LAUNCH_CHECK("attn_bwd_kernel");
     return MMT_OK;
 }
@@ -240,12 +242,11 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
                                    void* workspace, size_t workspace_bytes,
                                    int B, int T, int d, int h, int f, int n_layers, float eps,
                                    float dropout_p, uint64_t seed, mmt_stream_t stream) {
-    (void)seed;
     EncDims D;
     int rc = make_dims(D, B, T, d, h, f, n_layers);
     if (rc) return rc;
     if (!x || !mask || !params || !y || !workspace) return fail(MMT_EINVAL, "null pointer argument");
-    if (dropout_p != 0.f) return fail(MMT_EUNSUPPORTED, "train-mode dropout is not implemented yet (dropout_p must be 0)");
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(MMT_EINVAL, "dropout_p %g not in [0,1)", dropout_p);
     EncWs W; carve_encoder(W, D, workspace);
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -275,13 +276,15 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
             p.rowmask = mask; p.qscale = LOG2E / sqrtf((float)L.dk); p.scale_first = 1;
             if ((rc = launch_rowgemm<EPI_FRAG, true>(p, st, S_LN1_QKV))) return rc;
         }
-        if ((rc = launch_attn_fwd(L.DKP, w.QR, w.KR, w.VT, w.ctx, w.ctxT, w.lse, D, st))) return rc;
+        // dropout streams of layer l: 4l+0 attention probabilities (:33), 4l+1 / 4l+3 sublayer outputs (:104), 4l+2 FFN hidden (:20)
+        if ((rc = launch_attn_fwd(L.DKP, w.QR, w.KR, w.VT, w.ctx, w.ctxT, w.lse, D, st, make_drop(dropout_p, seed, 4 * l + 0)))) return rc;
         {   // output projection + residual
             RowGemmParams p = rg_zero();
             p.M = D.M; p.K = L.HDP; p.KP = L.HDP; p.N = d; p.NP = L.DP;
             p.A = w.ctx; p.a_bf16 = 1; p.lda = L.HDP;
             p.W = wp + L.pWo(); p.bias = bp + L.qbo();
             p.residual = xin; p.ldr = d; p.out_f32 = w.x1; p.ldo = d;
+            p.drop = make_drop(dropout_p, seed, 4 * l + 1);
             if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st, S_OUTPROJ))) return rc;
         }
         {   // LayerNorm 2 + first FFN product + ReLU
@@ -291,6 +294,7 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
             p.ln_a = P + L.oln(2); p.ln_b = P + L.oln(3); p.eps = eps; p.stats = w.stats2;
             p.W = wp + L.pW1(); p.bias = bp + L.qb1(); p.act = 1;
             p.out_bf16 = w.hid; p.ldo16 = L.FP; p.n_store16 = L.FP; p.out_T = w.hidT; p.ldoT = D.MP;
+            p.drop = make_drop(dropout_p, seed, 4 * l + 2);
             if ((rc = launch_rowgemm<EPI_PLAIN, true>(p, st, S_LN2_FFN1))) return rc;
         }
         {   // second FFN product + residual
@@ -299,6 +303,7 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
             p.A = w.hid; p.a_bf16 = 1; p.lda = L.FP;
             p.W = wp + L.pW2(); p.bias = bp + L.qb2();
             p.residual = w.x1; p.ldr = d; p.out_f32 = w.xout; p.ldo = d;
+            p.drop = make_drop(dropout_p, seed, 4 * l + 3);
             if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st, S_FFN2))) return rc;
         }
         xin = w.xout;
@@ -331,12 +336,11 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
                                     void* workspace, size_t workspace_bytes,
                                     int B, int T, int d, int h, int f, int n_layers, float eps,
                                     float dropout_p, uint64_t seed, mmt_stream_t stream) {
-    (void)seed;
     EncDims D;
     int rc = make_dims(D, B, T, d, h, f, n_layers);
     if (rc) return rc;
     if (!dy || !x || !mask || !params || !dx || !dparams || !workspace) return fail(MMT_EINVAL, "null pointer argument");
-    if (dropout_p != 0.f) return fail(MMT_EUNSUPPORTED, "train-mode dropout is not implemented yet (dropout_p must be 0)");
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(MMT_EINVAL, "dropout_p %g not in [0,1)", dropout_p);
     EncWs W; carve_encoder(W, D, workspace);
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -363,7 +367,9 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             p.M = D.M; p.K = d; p.KP = L.DP; p.N = f; p.NP = L.FP;
             p.A = cur; p.lda = d; p.At_out = W.dx2T; p.ldt = D.MP;
             p.W = wp + L.pW2T();
-            p.relu_mask = w.hid; p.ldm = L.FP;
+            p.relu_mask = w.hid; p.ldm = L.FP;          // hid > 0  <=>  ReLU passed AND the unit was kept
+            p.mask_scale = make_drop(dropout_p, seed, 4 * l + 2).scale;
+            p.a_drop = make_drop(dropout_p, seed, 4 * l + 3);   // gradient of the dropped sublayer-1 output
             p.out_bf16 = W.dh; p.ldo16 = L.FP; p.n_store16 = L.FP; p.out_T = W.dhT; p.ldoT = D.MP;
             if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st, S_BWD_FFN2))) return rc;
         }
@@ -381,13 +387,14 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             p.M = D.M; p.K = d; p.KP = L.DP; p.N = L.HD; p.NP = L.HDP;
             p.A = other; p.lda = d; p.At_out = W.dx1T; p.ldt = D.MP;
             p.W = wp + L.pWoT();
+            p.a_drop = make_drop(dropout_p, seed, 4 * l + 1);   // gradient of the dropped sublayer-0 output
             p.fragR[0] = W.dOR; p.fragT[0] = W.dOT;
             p.T = T; p.Tp = D.Tp; p.h = h; p.DKP = L.DKP; p.nwhich = 1;
             p.ctx = w.ctx; p.ldctx = L.HDP; p.delta = W.delta;
             if ((rc = launch_rowgemm<EPI_FRAG, false>(p, st, S_BWD_OUTPROJ))) return rc;
         }
         if ((rc = launch_attn_bwd(L.DKP, w.QR, w.QT, w.KR, w.KT, w.VR, W.dOR, W.dOT, w.lse, W.delta, W.dqslab,
-                                  W.dqkv, W.dqkvT, D, st))) return rc;
+                                  W.dqkv, W.dqkvT, D, st, make_drop(dropout_p, seed, 4 * l + 0)))) return rc;
         {
             ProfScope prof(S_DQ_FINISH, st);
             hipLaunchKernelGGL(dq_finish_kernel, dim3(grid_for((size_t)D.M * L.HD / 4)), dim3(256), 0, st,
@@ -776,7 +783,7 @@ static int check_mfn_dims(int mem_dim, int h_gamma) {
 
 extern "C" int mmt_mfn_mem_scan_forward(const float* apre, const float* chat, const float* Wm, const float* W2, const float* b2,
                                         float* mem_all, float* u_all, float* g_all, void* workspace, size_t workspace_bytes,
-                                        int T, int B, int mem_dim, int h_gamma, mmt_stream_t stream) {
+                                        int T, int B, int mem_dim, int h_gamma, float dropout_p, uint64_t seed, mmt_stream_t stream) {
     int rc = check_mfn_dims(mem_dim, h_gamma);
     if (rc) return rc;
     if (!apre || !chat || !Wm || !W2 || !b2 || !mem_all || !u_all || !g_all || !workspace) return fail(MMT_EINVAL, "null pointer argument");
@@ -786,7 +793,8 @@ extern "C" int mmt_mfn_mem_scan_forward(const float* apre, const float* chat, co
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(mfn_prep_kernel, dim3(64), dim3(256), 0, st, Wm, W2, W.WmF, W.W2F, W.WmB, W.W2B);
     LAUNCH_CHECK("mfn_prep_kernel");
-    hipLaunchKernelGGL(mfn_mem_scan_fwd_kernel, dim3((B + 15) / 16), dim3(512), 0, st, apre, chat, W.WmF, W.W2F, b2, mem_all, u_all, g_all, T, B);
+    hipLaunchKernelGGL(mfn_mem_scan_fwd_kernel, dim3((B + 15) / 16), dim3(512), 0, st, apre, chat, W.WmF, W.W2F, b2, mem_all, u_all, g_all, T, B,
+                       make_drop(dropout_p, seed, 1000));
     LAUNCH_CHECK("mfn_mem_scan_fwd_kernel");
     return MMT_OK;
 }
@@ -794,7 +802,7 @@ extern "C" int mmt_mfn_mem_scan_forward(const float* apre, const float* chat, co
 extern "C" int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* chat, const float* mem_all, const float* u_all,
                                          const float* g_all, const float* Wm, const float* W2,
                                          float* dchat, float* dapre, float* dz_all, void* workspace, size_t workspace_bytes,
-                                         int T, int B, int mem_dim, int h_gamma, mmt_stream_t stream) {
+                                         int T, int B, int mem_dim, int h_gamma, float dropout_p, mmt_stream_t stream) {
     int rc = check_mfn_dims(mem_dim, h_gamma);
     if (rc) return rc;
     if (!chat || !mem_all || !u_all || !g_all || !Wm || !W2 || !dchat || !dapre || !dz_all || !workspace) return fail(MMT_EINVAL, "null pointer argument");
@@ -805,7 +813,25 @@ extern "C" int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* cha
     hipLaunchKernelGGL(mfn_prep_kernel, dim3(64), dim3(256), 0, st, Wm, W2, W.WmF, W.W2F, W.WmB, W.W2B);
     LAUNCH_CHECK("mfn_prep_kernel");
     hipLaunchKernelGGL(mfn_mem_scan_bwd_kernel, dim3((B + 15) / 16), dim3(512), 0, st, dmem_all, chat, mem_all, u_all, g_all, W.WmB, W.W2B,
-                       dchat, dapre, dz_all, T, B);
+                       dchat, dapre, dz_all, T, B, make_drop(dropout_p, 0, 0).scale);
     LAUNCH_CHECK("mfn_mem_scan_bwd_kernel");
+    return MMT_OK;
+}
+
+
+// ------------------------------------------------------------------------------------ test hook
+// keep[i] = 1 if index i of dropout stream `stream` is kept under (p, seed): lets a test rebuild the exact masks the
+// kernels used and replay the reference arithmetic with them.
+__global__ void dropout_mask_kernel(DropCfg c, uint64_t n, uint8_t* __restrict__ keep) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        keep[i] = drop_keep(c, i) ? 1 : 0;
+}
+extern "C" int mmt_debug_dropout_mask(float p, uint64_t seed, uint32_t stream_id, uint64_t n, uint8_t* keep, float* scale_out,
+                                      mmt_stream_t stream) {
+    if (!keep) return fail(MMT_EINVAL, "null pointer argument");
+    const DropCfg c = make_drop(p, seed, stream_id);
+    if (scale_out) *scale_out = c.scale;        // host pointer
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), c, n, keep);
+    LAUNCH_CHECK("dropout_mask_kernel");
     return MMT_OK;
 }

@@ -21,7 +21,7 @@ template <int DKP>
 __global__ __launch_bounds__(MMT_THREADS) void attn_fwd_kernel(
         const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vt,
         bf16* __restrict__ ctx, bf16* __restrict__ ctxT, float* __restrict__ lse,
-        int h, int T, int nt, int ldc, int MP) {
+        int h, int T, int nt, int ldc, int MP, DropCfg drop) {
     constexpr int KS = DKP / 16;                       // k-steps over the head feature
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -68,6 +68,14 @@ __global__ __launch_bounds__(MMT_THREADS) void attn_fwd_kernel(
         for (int i = 0; i < 16; ++i) { s[i] = fast_exp2(s[i] - mnew); psum += s[i]; }
         lrun = lrun * alpha + psum;
         mrun = mnew;
+        if (drop.thr16) {      // dropout on the probabilities (reference :32-33); the normaliser keeps the undropped sum
+            const uint64_t base = ((uint64_t)bh * Tp + (uint64_t)(qt * 32 + r)) * Tp + (uint64_t)kt * 32;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {     // keys of registers (i, i+1) are adjacent: one hash word per pair
+                const uint32_t w = drop_pair(drop, base + acc32_row(i, hh));
+                s[i] = drop_lo(drop, w, s[i]); s[i + 1] = drop_hi(drop, w, s[i + 1]);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[i] *= alpha;
 #pragma unroll
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(MMT_THREADS) void attn_bwd_kernel(
         float* __restrict__ dq_slab,            // [nkb][M][ldq]
         bf16* __restrict__ dkv, int lddkv,      // row-major [M][lddkv]; dK at column HD, dV at 2*HD
         bf16* __restrict__ dkvT, int MP,        // T layout  [3*HD rows][MP]
-        int h, int T, int nt, int M, int ldq) {
+        int h, int T, int nt, int M, int ldq, DropCfg drop) {
     constexpr int KS = DKP / 16;
     constexpr int KB_TILES = 4 * KT;                   // key tiles per workgroup
     constexpr int LDS_ROW = KB_TILES * 32 + 8;         // bf16 elements per dS row (+8: bank spread)
@@ -189,6 +197,18 @@ __global__ __launch_bounds__(MMT_THREADS) void attn_bwd_kernel(
                 const float pv = ok ? fast_exp2(s[j]) : 0.f;
                 s[j] = pv;
                 ds[j] = pv * dp[j];
+            }
+            if (drop.thr16) {
+                // with dropped probabilities Pd = P*m/(1-p):  dV^T += dO^T Pd ;  dS = P * ((dO V^T)*m/(1-p) - delta)
+                // (delta = rowsum(dO.O) is unchanged); dp holds dO V^T - delta, negD holds -delta.
+                const uint64_t kcol = (uint64_t)ktile[i] * 32 + r;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint64_t idx = ((uint64_t)bh * Tp + (uint64_t)(qt * 32 + acc32_row(j, hh))) * Tp + kcol;
+                    const float ms = drop_keep(drop, idx) ? drop.scale : 0.f;
+                    ds[j] = s[j] * ((dp[j] - negD[j]) * ms + negD[j]);
+                    s[j] *= ms;
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {

@@ -69,11 +69,36 @@ __host__ __device__ __forceinline__ size_t fragT_elems(int Tp) { return (size_t)
 
 __host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-// counter-based hash RNG for dropout: one 32-bit word per (seed, stream, index)
-__device__ __forceinline__ uint32_t hash_u32(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx) {
-    uint32_t x = idx * 0x9E3779B1u + seed_lo;
-    x ^= x >> 16; x *= 0x85EBCA6Bu;
-    x ^= x >> 13; x += seed_hi; x *= 0xC2B2AE35u;
+// ---- dropout: counter-based generator.  One 32-bit hash word serves the index pair (2i, 2i+1); each
+// element compares its 16-bit half with thr16 = round(p * 65536): P(drop) = thr16/65536 (exact to 1.5e-5),
+// kept values are scaled by 65536/(65536 - thr16).  A mask is a pure function of (seed, stream, index), so the
+// backward pass regenerates it instead of storing it.
+struct DropCfg { uint32_t thr16; float scale; uint32_t s0, s1; };
+
+__device__ __forceinline__ uint32_t drop_word(uint32_t s0, uint32_t s1, uint32_t pair) {
+    uint32_t x = pair * 0x9E3779B1u + s0;
+    x ^= x >> 15; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x += s1; x *= 0xC2B2AE35u;
     x ^= x >> 16;
     return x;
+}
+__device__ __forceinline__ bool drop_keep(const DropCfg& c, uint64_t idx) {
+    const uint32_t w = drop_word(c.s0 + (uint32_t)(idx >> 33) * 0x7F4A7C15u, c.s1, (uint32_t)(idx >> 1));
+    return ((idx & 1) ? (w >> 16) : (w & 0xFFFFu)) >= c.thr16;
+}
+// pair form for an EVEN index: one hash word decides idx (low half) and idx+1 (high half)
+__device__ __forceinline__ uint32_t drop_pair(const DropCfg& c, uint64_t even_idx) {
+    return drop_word(c.s0 + (uint32_t)(even_idx >> 33) * 0x7F4A7C15u, c.s1, (uint32_t)(even_idx >> 1));
+}
+__device__ __forceinline__ float drop_lo(const DropCfg& c, uint32_t w, float v) { return (w & 0xFFFFu) >= c.thr16 ? v * c.scale : 0.f; }
+__device__ __forceinline__ float drop_hi(const DropCfg& c, uint32_t w, float v) { return (w >> 16) >= c.thr16 ? v * c.scale : 0.f; }
+// stream = which dropout site of which layer; keeps the sites statistically independent
+__host__ __device__ inline DropCfg make_drop(float p, uint64_t seed, uint32_t stream) {
+    DropCfg c;
+    double t = (double)p * 65536.0 + 0.5;
+    c.thr16 = p <= 0.f ? 0u : (t >= 65535.0 ? 65535u : (uint32_t)t);
+    c.scale = 65536.0f / (65536.0f - (float)c.thr16);
+    c.s0 = (uint32_t)seed ^ (stream * 0x632BE5ABu);
+    c.s1 = (uint32_t)(seed >> 32) + stream * 0x9E3779B9u;
+    return c;
 }

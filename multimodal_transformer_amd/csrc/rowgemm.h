@@ -24,13 +24,15 @@ struct RowGemmParams {
     // ---- A operand ----
     const void* A; int a_bf16; int lda;
     bf16* At_out; int ldt;                 // optional T-layout copy of the bf16 A tile: [KP][ldt]
+    DropCfg a_drop;                        // thr16 != 0: fp32 A is multiplied by the dropout mask of index m*KP + k on load
     // LayerNorm prologue (A must be fp32, K = feature count)
     const float* ln_a; const float* ln_b; float eps; float* stats;   // stats: [M][2] = (mean, 1/(std+eps))
     // ---- W operand: bf16 [NP][KP], zero padded; bias fp32 [NP] zero padded ----
     const bf16* W; const float* bias;
     // ---- PLAIN ----
     int act;                               // 1 = ReLU, 2 = tanh, 3 = sigmoid
-    const bf16* relu_mask; int ldm;        // multiply by (relu_mask[m][n] > 0)
+    const bf16* relu_mask; int ldm; float mask_scale;   // v = relu_mask[m][n] > 0 ? v * mask_scale : 0
+    DropCfg drop;                          // thr16 != 0: dropout after the activation, index m*NP + n
     const float* residual; int ldr;
     const float* rowscale;                 // multiply row m by rowscale[m]
     float* out_f32; int ldo;
@@ -130,6 +132,13 @@ __global__ __launch_bounds__(MMT_THREADS) void rowgemm_kernel(const RowGemmParam
             bf16x4 o = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
             if (m < M && c < K) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(A + (size_t)m * p.lda + c);
+                if (p.a_drop.thr16) {
+#pragma unroll
+                    for (int i = 0; i < 4; i += 2) {
+                        const uint32_t w = drop_pair(p.a_drop, (uint64_t)m * KP + c + i);
+                        v[i] = drop_lo(p.a_drop, w, v[i]); v[i + 1] = drop_hi(p.a_drop, w, v[i + 1]);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = (bf16)v[i];
             }
@@ -226,7 +235,14 @@ __global__ __launch_bounds__(MMT_THREADS) void rowgemm_kernel(const RowGemmParam
                     if (p.relu_mask) {
                         bf16x4 mk = *reinterpret_cast<const bf16x4*>(p.relu_mask + (size_t)m * p.ldm + n);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = ((float)mk[i] > 0.f) ? v[i] : 0.f;
+                        for (int i = 0; i < 4; ++i) v[i] = ((float)mk[i] > 0.f) ? v[i] * p.mask_scale : 0.f;
+                    }
+                    if (p.drop.thr16) {
+#pragma unroll
+                        for (int i = 0; i < 4; i += 2) {
+                            const uint32_t w = drop_pair(p.drop, (uint64_t)m * NP + n + i);
+                            v[i] = drop_lo(p.drop, w, v[i]); v[i + 1] = drop_hi(p.drop, w, v[i + 1]);
+                        }
                     }
                     if (p.residual) {
 #pragma unroll

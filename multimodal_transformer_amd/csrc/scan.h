@@ -236,7 +236,7 @@ __global__ void mfn_prep_kernel(const float* __restrict__ Wm, const float* __res
 __global__ __launch_bounds__(512) void mfn_mem_scan_fwd_kernel(
         const float* __restrict__ apre, const float* __restrict__ chat, const bf16* __restrict__ WmF,
         const bf16* __restrict__ W2F, const float* __restrict__ b2,
-        float* __restrict__ mem_all, float* __restrict__ u_all, float* __restrict__ g_all, int T, int B) {
+        float* __restrict__ mem_all, float* __restrict__ u_all, float* __restrict__ g_all, int T, int B, DropCfg drop) {
     __shared__ __attribute__((aligned(16))) bf16 membuf[16 * (MFN_MD + 8)];
     __shared__ __attribute__((aligned(16))) bf16 ubuf[16 * (MFN_U + 8)];
     constexpr int LDM = MFN_MD + 8, LDU = MFN_U + 8;
@@ -265,6 +265,13 @@ __global__ __launch_bounds__(512) void mfn_mem_scan_fwd_kernel(
             acc = mfma16(am[ks], *reinterpret_cast<const bf16x8*>(membuf + l15 * LDM + ks * 32 + 8 * lq), acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
+        if (drop.thr16) {          // gamma{1,2}_dropout on relu(fc1) (reference :222-223); u_all keeps the dropped values
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const uint32_t wd = drop_pair(drop, (uint64_t)row * MFN_U + j0 + r);
+                acc[r] = drop_lo(drop, wd, acc[r]); acc[r + 1] = drop_hi(drop, wd, acc[r + 1]);
+            }
+        }
         if (live) {
             *reinterpret_cast<f32x4*>(u_all + row * MFN_U + j0) = acc;
 #pragma unroll
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(512) void mfn_mem_scan_fwd_kernel(
 __global__ __launch_bounds__(512) void mfn_mem_scan_bwd_kernel(
         const float* __restrict__ dmem_ext, const float* __restrict__ chat, const float* __restrict__ mem_all,
         const float* __restrict__ u_all, const float* __restrict__ g_all, const bf16* __restrict__ WmB, const bf16* __restrict__ W2B,
-        float* __restrict__ dchat, float* __restrict__ dapre, float* __restrict__ dz_all, int T, int B) {
+        float* __restrict__ dchat, float* __restrict__ dapre, float* __restrict__ dz_all, int T, int B, float drop_scale) {
     __shared__ __attribute__((aligned(16))) bf16 zbuf[16 * (2 * MFN_MD + 8)];
     __shared__ __attribute__((aligned(16))) bf16 pbuf[16 * (MFN_U + 8)];
     constexpr int LDZ = 2 * MFN_MD + 8, LDP = MFN_U + 8;
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(512) void mfn_mem_scan_bwd_kernel(
         for (int ks = 0; ks < 4; ++ks)
             du = mfma16(a2[ks], *reinterpret_cast<const bf16x8*>(zbuf + l15 * LDZ + gsel * MFN_MD + ks * 32 + 8 * lq), du);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) du[r] = (uu[r] > 0.f) ? du[r] : 0.f;
+        for (int r = 0; r < 4; ++r) du[r] = (uu[r] > 0.f) ? du[r] * drop_scale : 0.f;   // u_all > 0 <=> relu passed AND kept
         if (live) {
             *reinterpret_cast<f32x4*>(dapre + row * MFN_U + j0) = du;
 #pragma unroll

@@ -252,7 +252,7 @@ class _MfnMemScanFn(torch.autograd.Function):
     (transformer/MFT/multiTransformer.py:221-224) with everything that does not depend on mem batched before."""
 
     @staticmethod
-    def forward(ctx, apre, chat, Wm, W2, b2):
+    def forward(ctx, apre, chat, Wm, W2, b2, dropout_p, seed):
         lib = _lib.load()
         _lib.require_hip(apre, chat, Wm, W2, b2)
         a_, c_, Wm_, W2_, b2_ = _f32c(apre), _f32c(chat), _f32c(Wm), _f32c(W2), _f32c(b2)
@@ -267,9 +267,11 @@ class _MfnMemScanFn(torch.autograd.Function):
         u_all = torch.empty(T, B, U, dtype=torch.float32, device=dev)
         g_all = torch.empty(T, B, 2 * MD, dtype=torch.float32, device=dev)
         _lib.check(lib.mmt_mfn_mem_scan_forward(_lib.ptr(a_), _lib.ptr(c_), _lib.ptr(Wm_), _lib.ptr(W2_), _lib.ptr(b2_), _lib.ptr(mem_all),
-                                                _lib.ptr(u_all), _lib.ptr(g_all), _lib.ptr(ws), nbytes, T, B, MD, HG, _lib.stream_ptr()))
+                                                _lib.ptr(u_all), _lib.ptr(g_all), _lib.ptr(ws), nbytes, T, B, MD, HG,
+                                                dropout_p, seed, _lib.stream_ptr()))
         ctx.save_for_backward(c_, Wm_, W2_, mem_all, u_all, g_all)
         ctx.dims = (T, B, U, MD, HG, nbytes)
+        ctx.dropout_p = dropout_p
         return mem_all
 
     @staticmethod
@@ -285,7 +287,7 @@ class _MfnMemScanFn(torch.autograd.Function):
         dz = torch.empty_like(g_all)
         _lib.check(lib.mmt_mfn_mem_scan_backward(_lib.ptr(dm), _lib.ptr(c_), _lib.ptr(mem_all), _lib.ptr(u_all), _lib.ptr(g_all), _lib.ptr(Wm_),
                                                  _lib.ptr(W2_), _lib.ptr(dchat), _lib.ptr(dapre), _lib.ptr(dz), _lib.ptr(ws), nbytes,
-                                                 T, B, MD, HG, _lib.stream_ptr()))
+                                                 T, B, MD, HG, ctx.dropout_p, _lib.stream_ptr()))
         M = T * B
         st = _lib.stream_ptr()
         # batched weight gradients (window contractions): dWm = dapre^T mem_prev ; dW2_g = dz_g^T u_g ; db2 = sum dz
@@ -304,8 +306,19 @@ class _MfnMemScanFn(torch.autograd.Function):
             lws2 = torch.zeros(lb2, dtype=torch.uint8, device=dev)
             _lib.check(lib.mmt_linear_backward(_lib.ptr(dzg), _lib.ptr(ug), _lib.ptr(W2_[g]), None, None, None, _lib.ptr(dW2[g]),
                                                _lib.ptr(db2[g]), _lib.ptr(lws2), lb2, M, HG, MD, 0, st))
-        return dapre, dchat, dWm, dW2, db2
+        return dapre, dchat, dWm, dW2, db2, None, None
 
 
-def mfn_mem_scan(apre, chat, Wm, W2, b2):
-    return _MfnMemScanFn.apply(apre, chat, Wm, W2, b2)
+def mfn_mem_scan(apre, chat, Wm, W2, b2, dropout_p=0.0, seed=0):
+    return _MfnMemScanFn.apply(apre, chat, Wm, W2, b2, float(dropout_p), int(seed))
+
+
+def dropout_mask(p, seed, stream_id, n, device):
+    """Test hook: (keep mask as a bool tensor of n entries, scale of kept values) of one dropout stream."""
+    import ctypes
+    lib = _lib.load()
+    keep = torch.empty(n, dtype=torch.uint8, device=device)
+    sc = ctypes.c_float(0.0)
+    _lib.check(lib.mmt_debug_dropout_mask(float(p), int(seed), int(stream_id), int(n), _lib.ptr(keep),
+                                          ctypes.cast(ctypes.pointer(sc), ctypes.c_void_p), _lib.stream_ptr()))
+    return keep.bool(), float(sc.value)

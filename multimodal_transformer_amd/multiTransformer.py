@@ -244,8 +244,11 @@ class MFN(nn.Module):
         self.to(self.device)
 
     def forward(self, inputs):
-        if self.training and (self.gamma1_dropout.p > 0 or self.out_dropout.p > 0):
-            raise NotImplementedError("MFN: train-mode dropout is not implemented yet; call .eval()")
+        pg = self.gamma1_dropout.p if self.training else 0.0        # gamma dropout runs inside the memory scan
+        if self.training and self.gamma2_dropout.p != self.gamma1_dropout.p:
+            raise NotImplementedError("MFN: gamma1_dropout and gamma2_dropout must share one probability")
+        self._seed_counter = getattr(self, "_seed_counter", 0) + 1
+        seed = (torch.initial_seed() * 1000003 + 7919 * self._seed_counter) & 0x7FFFFFFFFFFFFFFF
         hs, c_prev, c_new = [], [], []
         for mod in self.mods:
             cell = self.lstm[mod]
@@ -266,9 +269,10 @@ class MFN(nn.Module):
         apre = F_hip.linear(attended, w1[:, :A], torch.cat([self.gamma1_fc1.bias, self.gamma2_fc1.bias]))
         mem_all = F_hip.mfn_mem_scan(apre, c_hat, w1[:, A:],
                                      torch.stack([self.gamma1_fc2.weight, self.gamma2_fc2.weight]),
-                                     torch.stack([self.gamma1_fc2.bias, self.gamma2_fc2.bias]))
+                                     torch.stack([self.gamma1_fc2.bias, self.gamma2_fc2.bias]), dropout_p=pg, seed=seed)
         last = torch.cat(hs + [mem_all], dim=-1)
-        out = F_hip.linear(F_hip.linear(last, self.out_fc1.weight, self.out_fc1.bias, act=1), self.out_fc2.weight, self.out_fc2.bias)
+        hid = self.out_dropout(F_hip.linear(last, self.out_fc1.weight, self.out_fc1.bias, act=1))   # nn.Dropout: identity in eval
+        out = F_hip.linear(hid, self.out_fc2.weight, self.out_fc2.bias)
         return out.permute(1, 0, 2)
 
 

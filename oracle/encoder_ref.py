@@ -5,9 +5,11 @@ TEST INFRASTRUCTURE — see ``oracle/__init__.py``.  Each function names the ref
 it restates (paths relative to /root/reference/).  Everything is written dtype-generic so a
 test can run it in fp64 to obtain tight reference gradients through torch autograd.
 
-Eval-mode semantics only (every nn.Dropout of the reference is the identity): torch's
-dropout stream cannot be reproduced by the HIP path, so training-mode parity is
-statistical.
+Eval-mode by default (every nn.Dropout of the reference is the identity).  torch's dropout
+stream cannot be reproduced by the HIP path, so for train mode each function takes the
+dropout MULTIPLIERS explicitly (mask * 1/(1-p), shaped like the tensor nn.Dropout is applied
+to): a test extracts the masks the kernels used (mmt_debug_dropout_mask) and replays the
+reference arithmetic with them.
 """
 import math
 import re
@@ -28,8 +30,8 @@ def layer_norm(x, a_2, b_2, eps=1e-6):
     return a_2 * centred / (sigma + eps) + b_2
 
 
-def scaled_dot_attention(q, k, v, row_mask=None):
-    """transformer/MFT/multiTransformer.py:22-34 (dropout=None / eval).
+def scaled_dot_attention(q, k, v, row_mask=None, prob_drop=None):
+    """transformer/MFT/multiTransformer.py:22-34; ``prob_drop`` = multiplier of nn.Dropout on p_attn (:32-33).
 
     q, k, v: (B, h, T, d_k).  ``row_mask`` is the reference's (B, T, 1) float mask after
     ``unsqueeze(1)`` -> (B, 1, T, 1): it broadcasts along the KEY axis, so a zero entry
@@ -42,6 +44,8 @@ def scaled_dot_attention(q, k, v, row_mask=None):
         blank = (row_mask == 0)
         scores = torch.where(blank, torch.full_like(scores, -1e9), scores)
     probs = torch.softmax(scores, dim=-1)
+    if prob_drop is not None:
+        probs = probs * prob_drop
     return probs @ v, probs
 
 
@@ -49,7 +53,7 @@ def _affine(p, name, x):
     return x @ p[name + ".weight"].transpose(0, 1) + p[name + ".bias"]
 
 
-def multi_head_attention(p, prefix, query, key, value, mask, h):
+def multi_head_attention(p, prefix, query, key, value, mask, h, prob_drop=None):
     """transformer/MFT/multiTransformer.py:47-65.  ``prefix`` ends before ``linears``."""
     B, d = query.shape[0], query.shape[-1]
     d_k = d // h
@@ -61,22 +65,29 @@ def multi_head_attention(p, prefix, query, key, value, mask, h):
     q = split(_affine(p, prefix + "linears.0", query))
     k = split(_affine(p, prefix + "linears.1", key))
     v = split(_affine(p, prefix + "linears.2", value))
-    ctx, _ = scaled_dot_attention(q, k, v, row_mask)
+    ctx, _ = scaled_dot_attention(q, k, v, row_mask, prob_drop)
     merged = ctx.permute(0, 2, 1, 3).reshape(B, -1, h * d_k)
     return _affine(p, prefix + "linears.3", merged)
 
 
-def feed_forward(p, prefix, x):
-    """transformer/MFT/multiTransformer.py:19-20 (eval)."""
-    return _affine(p, prefix + "w_2", torch.relu(_affine(p, prefix + "w_1", x)))
+def feed_forward(p, prefix, x, hidden_drop=None):
+    """transformer/MFT/multiTransformer.py:19-20; ``hidden_drop`` = multiplier of the dropout after the ReLU."""
+    hid = torch.relu(_affine(p, prefix + "w_1", x))
+    if hidden_drop is not None:
+        hid = hid * hidden_drop
+    return _affine(p, prefix + "w_2", hid)
 
 
-def encoder_layer(p, prefix, x, mask, h):
-    """transformer/MFT/multiTransformer.py:103-104 and :114-116 (pre-norm residual, eval)."""
+def encoder_layer(p, prefix, x, mask, h, drops=None):
+    """transformer/MFT/multiTransformer.py:103-104 and :114-116 (pre-norm residual).
+    ``drops``: None (eval) or {"attn": (B,h,T,T), "sub0": (B,T,d), "ffn": (B,T,f), "sub1": (B,T,d)} multipliers."""
+    dr = drops or {}
     n0 = layer_norm(x, p[prefix + "sublayer.0.norm.a_2"], p[prefix + "sublayer.0.norm.b_2"])
-    x = x + multi_head_attention(p, prefix + "self_attn.", n0, n0, n0, mask, h)
+    a = multi_head_attention(p, prefix + "self_attn.", n0, n0, n0, mask, h, dr.get("attn"))
+    x = x + (a * dr["sub0"] if "sub0" in dr else a)
     n1 = layer_norm(x, p[prefix + "sublayer.1.norm.a_2"], p[prefix + "sublayer.1.norm.b_2"])
-    return x + feed_forward(p, prefix + "feed_forward.", n1)
+    f = feed_forward(p, prefix + "feed_forward.", n1, dr.get("ffn"))
+    return x + (f * dr["sub1"] if "sub1" in dr else f)
 
 
 def count_layers(p, prefix):
@@ -85,8 +96,8 @@ def count_layers(p, prefix):
     return max(idx) + 1 if idx else 0
 
 
-def encoder_stack(p, prefix, x, mask, h):
-    """transformer/MFT/multiTransformer.py:73-76: N layers, then the final LayerNorm."""
+def encoder_stack(p, prefix, x, mask, h, drops=None):
+    """transformer/MFT/multiTransformer.py:73-76: N layers, then the final LayerNorm.  ``drops``: per-layer list."""
     for i in range(count_layers(p, prefix)):
-        x = encoder_layer(p, "%slayers.%d." % (prefix, i), x, mask, h)
+        x = encoder_layer(p, "%slayers.%d." % (prefix, i), x, mask, h, None if drops is None else drops[i])
     return layer_norm(x, p[prefix + "norm.a_2"], p[prefix + "norm.b_2"])

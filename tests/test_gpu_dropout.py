@@ -1,0 +1,124 @@
+"""Train-mode (dropout) tests of the fused encoder path on the GPU.
+
+torch's dropout stream cannot be reproduced in HIP, so train-mode parity is established in two ways:
+  * REPLAY (numerical): the exact keep-masks the kernels used are rebuilt with mmt_debug_dropout_mask and the
+    oracle is run with those masks as explicit multipliers at the reference's four dropout sites
+    (attention probabilities :33, FFN hidden :20, both sublayer outputs :104).  Same tolerances as eval mode.
+  * STATISTICAL: drop fraction = p within 4 sigma; kept values scaled by 1/(1-p); masks are deterministic in
+    (seed, stream, index) and independent across streams/seeds.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import recipe as R
+from test_gpu_parity import OUT_RTOL, RELU_GRAD_RTOL, CCC_MIN, _report, mta
+from conftest import grad_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _masks(dev, p, seed, n_layers, B, T, d, h, f):
+    F = mta().functional
+    Tp, DP, FP = -(-T // 32) * 32, -(-d // 64) * 64, -(-f // 64) * 64
+    M = B * T
+    out = []
+    for l in range(n_layers):
+        ka, sa = F.dropout_mask(p, seed, 4 * l + 0, B * h * Tp * Tp, dev)
+        k0, s0 = F.dropout_mask(p, seed, 4 * l + 1, M * DP, dev)
+        kf, sf = F.dropout_mask(p, seed, 4 * l + 2, M * FP, dev)
+        k1, s1 = F.dropout_mask(p, seed, 4 * l + 3, M * DP, dev)
+        out.append({
+            "attn": (ka.reshape(B, h, Tp, Tp)[:, :, :T, :T].double() * sa).cpu(),
+            "sub0": (k0.reshape(B, T, DP)[:, :, :d].double() * s0).cpu(),
+            "ffn": (kf.reshape(B, T, FP)[:, :, :f].double() * sf).cpu(),
+            "sub1": (k1.reshape(B, T, DP)[:, :, :d].double() * s1).cpu(),
+        })
+    return out
+
+
+@pytest.mark.parametrize("d,h,n,B,T,lengths,p", [(128, 8, 2, 3, 50, [50, 31, 6], 0.1), (40, 4, 2, 2, 33, [33, 9], 0.25),
+                                                 (256, 8, 1, 2, 70, [70, 64], 0.1)])
+def test_train_mode_replay_with_kernel_masks(dev, d, h, n, B, T, lengths, p):
+    MT = mta().multiTransformer
+    F = mta().functional
+    enc = MT.Encoder(MT.EncoderLayer(d, MT.MultiHeadedAttention(h, d), MT.PositionwiseFeedForward(d, R.D_FF, p), p), n)
+    p32 = R.gen_params(R.shapes_of(enc.state_dict()), 31)
+    enc.load_state_dict(p32)
+    enc = enc.to(dev).train()
+    x = R.gen_normal("drop:x%d" % d, (B, T, d), 31)
+    g = R.gen_normal("drop:g%d" % d, (B, T, d), 31)
+    mask = R.prefix_mask(lengths, T)
+    seed = 123456789 + d
+    flat = torch.cat([q.reshape(-1) for q in enc.flat_parameters()]).detach().requires_grad_()
+    xg = x.to(dev).requires_grad_()
+    y = F.encoder_stack(xg, mask.to(dev), flat, h, R.D_FF, n, dropout_p=p, seed=seed)
+    (y * g.to(dev)).sum().backward()
+    drops = _masks(dev, p, seed, n, B, T, d, h, R.D_FF)
+    frac = float(1 - (drops[0]["ffn"] > 0).double().mean())
+    assert abs(frac - p) < 4 * np.sqrt(p * (1 - p) / drops[0]["ffn"].numel()) + 2e-5
+
+    pd = {k: v.double().clone().requires_grad_() for k, v in p32.items()}
+    xd = x.double().clone().requires_grad_()
+    ref = oracle.encoder_stack(pd, "", xd, mask.double(), h, drops)
+    (ref * g.double()).sum().backward()
+    tag = "train d%d p%.2f" % (d, p)
+    assert _report(tag + " out", y.detach().cpu(), ref.detach()) < OUT_RTOL
+    assert mta().eval_ccc(ref.detach().numpy(), y.detach().cpu().numpy()) >= CCC_MIN
+    assert _report(tag + " dx", xg.grad.cpu(), xd.grad) < RELU_GRAD_RTOL
+    ref_flat = torch.cat([pd[k].grad.reshape(-1) for k in _flat_names(n)])
+    assert _report(tag + " dparams", flat.grad.cpu(), ref_flat) < RELU_GRAD_RTOL
+    # and it must differ from the eval-mode result (dropout really happened)
+    with torch.no_grad():
+        y_eval = F.encoder_stack(x.to(dev), mask.to(dev), flat.detach(), h, R.D_FF, n)
+    assert float((y_eval - y.detach()).abs().max()) > 1e-2
+
+
+def _flat_names(n):
+    names = []
+    for i in range(n):
+        L = "layers.%d." % i
+        for j in range(4):
+            names += [L + "self_attn.linears.%d.weight" % j, L + "self_attn.linears.%d.bias" % j]
+        names += [L + "feed_forward.w_1.weight", L + "feed_forward.w_1.bias", L + "feed_forward.w_2.weight", L + "feed_forward.w_2.bias",
+                  L + "sublayer.0.norm.a_2", L + "sublayer.0.norm.b_2", L + "sublayer.1.norm.a_2", L + "sublayer.1.norm.b_2"]
+    return names + ["norm.a_2", "norm.b_2"]
+
+
+def test_mask_statistics_and_determinism(dev):
+    F = mta().functional
+    n = 1 << 20
+    for p in (0.1, 0.2, 0.5):
+        k1, s1 = F.dropout_mask(p, 42, 3, n, dev)
+        k2, _ = F.dropout_mask(p, 42, 3, n, dev)
+        k3, _ = F.dropout_mask(p, 43, 3, n, dev)
+        k4, _ = F.dropout_mask(p, 42, 4, n, dev)
+        assert torch.equal(k1, k2)                                  # pure function of (p, seed, stream, index)
+        frac = 1 - k1.float().mean().item()
+        assert abs(frac - p) < 4 * np.sqrt(p * (1 - p) / n) + 2e-5
+        assert abs(s1 - 1 / (1 - round(p * 65536) / 65536)) < 1e-6
+        for other in (k3, k4):                                      # independent streams: agreement = p^2 + (1-p)^2
+            agree = (k1 == other).float().mean().item()
+            assert abs(agree - (p * p + (1 - p) * (1 - p))) < 6e-3
+        pairs = k1.reshape(-1, 2).float()                           # the two halves of one hash word are uncorrelated
+        c = np.corrcoef(pairs[:, 0].cpu().numpy(), pairs[:, 1].cpu().numpy())[0, 1]
+        assert abs(c) < 6e-3
+
+
+def test_module_train_mode_runs_and_reseeds(dev):
+    MT = mta().multiTransformer
+    enc = MT.Encoder(MT.EncoderLayer(128, MT.MultiHeadedAttention(8, 128), MT.PositionwiseFeedForward(128, 128, 0.1), 0.1), 2).to(dev)
+    enc.train()
+    x = R.gen_normal("drop:mod", (2, 40, 128), 5).to(dev)
+    mask = torch.ones(2, 40, 1, device=dev)
+    y1, y2 = enc(x, mask), enc(x, mask)
+    assert torch.isfinite(y1).all() and float((y1 - y2).abs().max()) > 1e-3      # a fresh mask per call
+    enc.eval()
+    assert torch.equal(enc(x, mask), enc(x, mask))
