@@ -3,17 +3,19 @@
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
-One step = one forward + loss + backward pass (all input, weight and LayerNorm gradients) of the
-encoder stack over one synthetic batch already resident in HBM; with N>1 each rank holds its own
+One step = one TRAIN-MODE (dropout 0.1) forward + MSE loss + backward pass (all input, weight and
+LayerNorm gradients) over one synthetic batch already resident in HBM; with N>1 each rank holds its own
 B sequences (weak scaling) and the step ends with the RCCL SUM all-reduce of the gradients.
 A window is one time-step of one sequence: windows/step = N*B*T.
 
-Rank 0 prints ONE JSON line carrying, besides the contract fields,
+Primary workload (`value`): the encoder-stack hot path of the SFT configuration the metric is quoted on
+(C4: T=500, d_model=128, heads=8, N=6, d_ff=128, 32 sequences per GPU).  Rank 0 prints ONE JSON line with
   roofline     — the dominant kernel of the step (by HIP-event time measured here, on the stream the
-                 kernels run on), its algorithmic FLOPs per launch / average duration vs the dense
-                 bf16 MFMA peak;
-  cpu_baseline — the CPU oracle (a port of the reference path, fp32 torch CPU) timed on this box's
-                 host cores on a bounded sample of the same workload.
+                 kernels run on): algorithmic FLOPs per launch / average duration vs the dense bf16 MFMA peak;
+  cpu_baseline — the CPU oracle (a port of the reference path, fp32 torch CPU) timed on this box's host
+                 cores on a bounded sample of the same workload;
+  full_model   — (N=1) the whole SFT sequence model NLPTransformer(512 -> d): embed + encoder + LSTM
+                 decoder + MLP + mask, same batch shape, for the end-to-end picture.
 """
 import argparse
 import json
@@ -35,6 +37,7 @@ WORKLOADS = {
     "C3e": dict(desc="MFT per-modality encoder stack T=300 d_model=256 heads=8 N=6 d_ff=128, 32 sequences/GPU", B=32, T=300, d=256, h=8, N=6, f=128),
     "C5e": dict(desc="MFT per-modality encoder stack T=1000 d_model=256 heads=8 N=6 d_ff=128, 64 sequences/GPU", B=64, T=1000, d=256, h=8, N=6, f=128),
 }
+DROPOUT = 0.1
 
 
 def flops_per_window_layer_fwd(d, T, f):
@@ -60,12 +63,11 @@ def site_flops_per_launch(site, M, T, d, f):
     return table.get(site, 0) * M
 
 
-def build_encoder(cfg, dev):
+def make_encoder(cfg):
     from multimodal_transformer_amd import multiTransformer as MT
     torch.manual_seed(1)                                    # transformer/SFT/train.py:522
-    enc = MT.Encoder(MT.EncoderLayer(cfg["d"], MT.MultiHeadedAttention(cfg["h"], cfg["d"]),
-                                     MT.PositionwiseFeedForward(cfg["d"], cfg["f"], 0.1), 0.1), cfg["N"])
-    return enc.to(dev)
+    return MT.Encoder(MT.EncoderLayer(cfg["d"], MT.MultiHeadedAttention(cfg["h"], cfg["d"]),
+                                      MT.PositionwiseFeedForward(cfg["d"], cfg["f"], DROPOUT), DROPOUT), cfg["N"])
 
 
 def cpu_baseline(cfg, seconds_budget=15.0):
@@ -74,10 +76,7 @@ def cpu_baseline(cfg, seconds_budget=15.0):
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(cores, 16)          # the GPU box gives one GPU a 16-CPU share; more threads only oversubscribe it
     torch.set_num_threads(cores)
-    from multimodal_transformer_amd import multiTransformer as MT
-    torch.manual_seed(1)
-    enc = MT.Encoder(MT.EncoderLayer(cfg["d"], MT.MultiHeadedAttention(cfg["h"], cfg["d"]),
-                                     MT.PositionwiseFeedForward(cfg["d"], cfg["f"], 0.1), 0.1), cfg["N"])
+    enc = make_encoder(cfg)
     p = {k: v.detach().clone().requires_grad_() for k, v in enc.state_dict().items()}
     Bs = max(1, min(cfg["B"], 4))
     T, d = cfg["T"], cfg["d"]
@@ -101,9 +100,70 @@ def cpu_baseline(cfg, seconds_budget=15.0):
         if time.perf_counter() - t0 > seconds_budget or n >= 10:
             break
     dt = (time.perf_counter() - t0) / n
-    return {"value": Bs * T / dt, "unit": "windows/s", "cores": cores, "kind": "port",
-            "sample": "%d steps of the CPU oracle (fp32 torch-CPU port of the reference path) on %d of the %d sequences, same T/d/h/N, "
-                      "eval-mode arithmetic; %.2f s/step" % (n, Bs, cfg["B"], dt)}
+    return {"value": round(Bs * T / dt, 1), "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of the CPU oracle (fp32 torch-CPU port of the reference path, dropout as identity) on %d of the %d "
+                      "sequences, same T/d/h/N; %.3f s/step" % (n, Bs, cfg["B"], dt)}
+
+
+class Runner:
+    """warm-up, optional hipGraph capture, timed loop of `fwd_bwd` (+ gradient all-reduce when world > 1)."""
+
+    def __init__(self, fwd_bwd, params, world, use_graph, warmup):
+        from multimodal_transformer_amd import parallel
+        self.fwd_bwd, self.params, self.world, self.parallel = fwd_bwd, params, world, parallel
+        self.graph, self.launch = None, "eager"
+        for _ in range(max(1, warmup)):
+            self.eager()
+        torch.cuda.synchronize()
+        if use_graph:
+            try:
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    for _ in range(2):
+                        fwd_bwd()
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fwd_bwd()
+                self.graph, self.launch = g, "hipgraph"
+            except Exception as e:  # noqa: BLE001
+                print("graph capture failed (%s); falling back to eager launches" % str(e).splitlines()[0], file=sys.stderr)
+                self.graph = None
+                torch.cuda.synchronize()
+        for _ in range(max(1, warmup)):
+            self.step()
+        torch.cuda.synchronize()
+
+    def eager(self):
+        self.fwd_bwd()
+        self.parallel.allreduce_gradients(self.params)
+
+    def step(self):
+        if self.graph is not None:
+            self.graph.replay()
+            self.parallel.allreduce_gradients(self.params)
+        else:
+            self.eager()
+
+    def timed(self, steps, dist=None, dev=None):
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if self.world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
 
 
 def main():
@@ -114,15 +174,16 @@ def main():
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-model", action="store_true")
+    ap.add_argument("--eval-mode", action="store_true", help="dropout as identity (parity-test arithmetic) instead of train mode")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra eager steps with per-kernel HIP-event timing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if world == 1 and args.gpus > 1:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -131,12 +192,14 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    from multimodal_transformer_amd import _lib, parallel
+    from multimodal_transformer_amd import _lib
     cfg = WORKLOADS[args.workload]
     B, T, d, h, N, f = (cfg[k] for k in ("B", "T", "d", "h", "N", "f"))
     M = B * T
-    enc = build_encoder(cfg, dev).eval()       # eval-mode arithmetic: train-mode dropout kernels are not implemented yet
-    params = [p for p in enc.parameters()]
+    train = not args.eval_mode
+    enc = make_encoder(cfg).to(dev)
+    enc.train(train)
+    params = list(enc.parameters())
     g = torch.Generator(device="cpu").manual_seed(1 + rank)
     x = torch.randn(B, T, d, generator=g).to(dev).requires_grad_()
     tgt = torch.rand(B, T, d, generator=g).to(dev)
@@ -147,66 +210,11 @@ def main():
         for p in params:
             p.grad = None
         x.grad = None
-        y = enc(x, mask)
-        loss = ((y - tgt) ** 2).sum() / nvalid
+        loss = ((enc(x, mask) - tgt) ** 2).sum() / nvalid
         loss.backward()
-        return loss
 
-    def step_eager():
-        fwd_bwd()
-        parallel.allreduce_gradients(params)
-
-    # ---- warm-up (also creates the pooled workspace before any capture)
-    for _ in range(max(1, args.warmup)):
-        step_eager()
-    torch.cuda.synchronize()
-
-    launch = "eager"
-    graph = None
-    if not args.no_graph:
-        try:
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for _ in range(2):
-                    fwd_bwd()
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                fwd_bwd()
-            launch = "hipgraph"
-        except Exception as e:  # noqa: BLE001
-            if rank == 0:
-                print("graph capture failed (%s); falling back to eager launches" % str(e).splitlines()[0], file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-
-    def step():
-        if graph is not None:
-            graph.replay()
-            parallel.allreduce_gradients(params)
-        else:
-            step_eager()
-
-    for _ in range(max(1, args.warmup)):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    run = Runner(fwd_bwd, params, world, not args.no_graph, args.warmup)
+    elapsed = run.timed(args.steps, dist, dev)
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * M * args.steps / elapsed
 
@@ -220,8 +228,7 @@ def main():
         prof = _lib.profile_collect()
         _lib.profile(False)
         kernel_ms = {k: round(v[0] / args.profile_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
-        dom = max(prof.items(), key=lambda kv: kv[1][0])
-        name, (tot_ms, cnt) = dom
+        name, (tot_ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
         avg_s = tot_ms / cnt * 1e-3
         fl = site_flops_per_launch(name, M, T, d, f)
         ach = fl / avg_s / 1e12 if avg_s > 0 else 0.0
@@ -230,6 +237,37 @@ def main():
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": cnt // args.profile_steps,
                     "flops_per_launch": fl,
                     "share_of_kernel_time": round(tot_ms / sum(v[0] for v in prof.values()), 3)}
+
+    # ---- whole SFT sequence model, same batch shape (N=1 only)
+    full = None
+    if rank == 0 and world == 1 and not args.no_full_model and args.workload in ("C4", "C2"):
+        from multimodal_transformer_amd import multiTransformer as MT
+        torch.manual_seed(1)
+        model = MT.NLPTransformer(512, embed_dim=d, h=h, N=N, d_ff=f, dropout=DROPOUT, device=dev)
+        model.train(train)
+        mparams = list(model.parameters())
+        xin = torch.tanh(torch.randn(B, T, 512, generator=g)).to(dev)      # post-fusion tanh features (SFT/models.py:138)
+        tgt1 = torch.rand(B, T, 1, generator=g).to(dev)
+        lengths = [T] * B
+
+        def model_step():
+            for p in mparams:
+                p.grad = None
+            loss = ((model(xin, mask, lengths) - tgt1) ** 2).sum() / float(B * T)
+            loss.backward()
+
+        mrun = Runner(model_step, mparams, 1, not args.no_graph, 3)
+        el = mrun.timed(max(5, args.steps // 2))
+        nst = max(5, args.steps // 2)
+        _lib.profile(True)
+        for _ in range(3):
+            model_step()
+        torch.cuda.synchronize()
+        mp_ = _lib.profile_collect()
+        _lib.profile(False)
+        full = {"model": "NLPTransformer(512, embed_dim=%d, h=%d): Dropout+Linear+ReLU embed, encoder, LSTM decoder, MLP, mask" % (d, h),
+                "value": round(M * nst / el, 1), "unit": "windows/s", "ms_per_step": round(1e3 * el / nst, 4), "launch": mrun.launch,
+                "kernel_ms_per_step": {k: round(v[0] / 3, 4) for k, v in sorted(mp_.items(), key=lambda kv: -kv[1][0])[:8]}}
 
     if rank == 0:
         fpw = 3 * N * flops_per_window_layer_fwd(d, T, f)
@@ -240,14 +278,18 @@ def main():
             "config": {"workload": cfg["desc"] + "; fwd + MSE loss + bwd (input, weight, LayerNorm grads)"
                        + ("; + RCCL SUM all-reduce of gradients" if world > 1 else ""),
                        "name": args.workload, "global_batch": world * B, "seq_len": T, "d_model": d, "heads": h, "layers": N, "d_ff": f,
-                       "parallelism": "dp%d" % world, "dropout": "off (eval-mode arithmetic; train-mode dropout kernels not implemented yet)",
+                       "parallelism": "dp%d" % world,
+                       "dropout": ("train mode, p=%.2f at the reference's four encoder sites, in-kernel generator" % DROPOUT) if train
+                       else "eval mode (identity)",
                        "lengths": "full"},
-            "launch": launch,
+            "launch": run.launch,
             "algorithmic_mflop_per_window": round(fpw / 1e6, 3),
             "step_mfma_frac": round(value * fpw / (world * MFMA_BF16_PEAK_TFLOPS * 1e12), 5),
             "roofline": roofline,
             "kernel_ms_per_step": kernel_ms,
         }
+        if full is not None:
+            out["full_model"] = full
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))

@@ -140,11 +140,12 @@ int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* chat, const fl
 
 /* ---- Test hook: the keep-mask (1 = kept) of dropout stream `stream_id` for indices [0,n) under (p, seed), and the
  * scale applied to kept values (host pointer, may be NULL).  Streams used by the encoder stack for layer l:
- * 4l+0 attention probabilities, index ((b*h+head)*Tp + q)*Tp + key (Tp = T rounded up to 32);
+ * 4l+0 attention probabilities, index ((b*h+head)*Tp + q)*Tp + key (Tp = T rounded up to 32; pass attn_Tp = Tp,
+ *      0 for every other stream);
  * 4l+1 / 4l+3 sublayer outputs and 4l+2 FFN hidden, index m*NP + n (NP = width rounded up to 64);
  * 1000: MFN gamma hidden, index (t*B+b)*128 + j. */
-int mmt_debug_dropout_mask(float p, uint64_t seed, uint32_t stream_id, uint64_t n, uint8_t* keep, float* host_scale_out,
-                           mmt_stream_t stream);
+int mmt_debug_dropout_mask(float p, uint64_t seed, uint32_t stream_id, uint64_t n, uint32_t attn_Tp, uint8_t* keep,
+                           float* host_scale_out, mmt_stream_t stream);
 
 #ifdef __cplusplus
 }

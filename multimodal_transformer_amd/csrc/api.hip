@@ -30,12 +30,15 @@ static int fail(int code, const char* fmt, ...) {
 // Optional HIP-event bracket around every launch site (eager mode only), so bench.py can report the
 // dominant kernel's average duration on the stream the kernels really run on.
 enum Site { S_PREP = 0, S_LN1_QKV, S_ATTN_FWD, S_OUTPROJ, S_LN2_FFN1, S_FFN2, S_LN_FWD, S_LN_BWD, S_BWD_FFN2, S_BWD_FFN1_LN2,
-            S_BWD_OUTPROJ, S_ATTN_BWD, S_DQ_FINISH, S_BWD_QKV_LN1, S_WGRAD, S_FINALIZE, S_OTHER, S_COUNT };
+            S_BWD_OUTPROJ, S_ATTN_BWD, S_DQ_FINISH, S_BWD_QKV_LN1, S_WGRAD, S_FINALIZE, S_OTHER,
+            S_LINEAR_FWD, S_LINEAR_BWD_DX, S_LINEAR_WGRAD, S_LSTM_FWD, S_LSTM_BWD, S_MEM_FWD, S_MEM_BWD, S_COUNT };
 static const char* const g_site_names[S_COUNT] = {
     "encoder_prep_kernel", "rowgemm<FRAG,LN>:ln1+qkv", "attn_fwd_kernel", "rowgemm<PLAIN>:outproj+res",
     "rowgemm<PLAIN,LN>:ln2+ffn1+relu", "rowgemm<PLAIN>:ffn2+res", "layernorm_fwd_kernel", "layernorm_bwd_kernel",
-    "rowgemm<PLAIN>:bwd_ffn2", "rowgemm<LNBWD>:bwd_ffn1+ln2", "rowgemm<FRAG>:bwd_outproj->dO", "attn_bwd_kernel",
-    "dq_finish_kernel", "rowgemm<LNBWD>:bwd_qkv+ln1", "wgrad_kernel", "finalize_kernels", "other"};
+    "rowgemm<PLAIN>:bwd_ffn2", "rowgemm<LNBWD>:bwd_ffn1+ln2", "rowgemm<FRAG>:bwd_outproj->dO", "attn_bwd_dkv_kernel",
+    "attn_bwd_dq_kernel", "rowgemm<LNBWD>:bwd_qkv+ln1", "wgrad_kernel", "finalize_kernels", "other",
+    "rowgemm<PLAIN>:linear_fwd", "rowgemm<PLAIN>:linear_bwd_dx", "wgrad_kernel:linear", "lstm_scan_fwd_kernel", "lstm_scan_bwd_kernel",
+    "mfn_mem_scan_fwd_kernel", "mfn_mem_scan_bwd_kernel"};
 struct ProfRec { int site; hipEvent_t a, b; };
 static bool g_prof = false;
 static ProfRec* g_recs = nullptr;
@@ -89,12 +92,11 @@ struct Carver {
     }
 };
 
-static constexpr int KT_BWD = 2;            // key tiles per wave in attn_bwd (workgroup = 256 keys)
 static constexpr int MAX_LAYERS = 16;
 
 struct EncDims {
     int B, T, d, h, f, N;
-    int M, MP, Tp, nt, G, nkb, nsplit, mchunk, M16;
+    int M, MP, Tp, nt, G, nsplit, mchunk, M16;
     LayerLayout L;
 };
 
@@ -108,7 +110,6 @@ static int make_dims(EncDims& D, int B, int T, int d, int h, int f, int N) {
     D.B = B; D.T = T; D.d = d; D.h = h; D.f = f; D.N = N;
     D.M = B * T; D.MP = round_up(D.M, 64); D.M16 = round_up(D.M, 16);
     D.Tp = round_up(T, 32); D.nt = D.Tp / 32; D.G = (D.M + 31) / 32;
-    D.nkb = (D.nt + 4 * KT_BWD - 1) / (4 * KT_BWD);
     D.L = make_layout(d, f, h);
     // weight-gradient split over windows: aim for >= 512 workgroups
     const LayerLayout& L = D.L;
@@ -127,7 +128,7 @@ struct EncWs {
     bf16* wprep; float* bprep; float* statsf;
     LayerWs lw[MAX_LAYERS];
     // backward scratch (shared by all layers; single stream)
-    float *dxa, *dxb, *delta, *dqslab, *lnpart1, *lnpart2;
+    float *dxa, *dxb, *delta, *lnpart1, *lnpart2;
     bf16 *dx2T, *dh, *dhT, *dx1T, *dOR, *dOT, *dqkv, *dqkvT;
     float *sWqkv, *sbqkv, *sWo, *sbo, *sW1, *sb1, *sW2, *sb2;
     size_t bytes;
@@ -155,7 +156,6 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
     }
     W.dxa = c.take<float>(M * D.d); W.dxb = c.take<float>(M * D.d);
     W.delta = c.take<float>(BH * D.Tp);
-    W.dqslab = c.take<float>((size_t)D.nkb * M * L.HDP);
     W.lnpart1 = c.take<float>((size_t)D.G * 2 * L.DP); W.lnpart2 = c.take<float>((size_t)D.G * 2 * L.DP);
     W.dx2T = c.take<bf16>((size_t)L.DP * MP); W.dh = c.take<bf16>(M * L.FP); W.dhT = c.take<bf16>((size_t)L.FP * MP);
     W.dx1T = c.take<bf16>((size_t)L.DP * MP);
@@ -195,24 +195,39 @@ static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* 
                            const EncDims& D, hipStream_t st, DropCfg drop = no_drop()) {
     dim3 grid((D.nt + 3) / 4, D.B * D.h);
     ProfScope prof(S_ATTN_FWD, st);
-    if (DKP == 16) hipLaunchKernelGGL((attn_fwd_kernel<16>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, D.h, D.T, D.nt, D.L.HDP, D.MP, drop);
-    else hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, D.h, D.T, D.nt, D.L.HDP, D.MP, drop);
+#define MMT_FWD(dkp, dr) hipLaunchKernelGGL((attn_fwd_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, \
+                                            D.h, D.T, D.nt, D.L.HDP, D.MP, drop)
+    if (DKP == 16) { if (drop.thr16) MMT_FWD(16, true); else MMT_FWD(16, false); }
+    else { if (drop.thr16) MMT_FWD(32, true); else MMT_FWD(32, false); }
+#undef MMT_FWD
     LAUNCH_CHECK("attn_fwd_kernel");
     return MMT_OK;
 }
 
+// dQ, dK, dV -> bf16 row-major dqkv [M][NQ] (columns: dQ | dK | dV, heads padded) and its T layout [NQ][MP]
 static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* KR, const bf16* KT_, const bf16* VR,
-                           const bf16* dOR, const bf16* dOT, const float* lse, const float* delta, float* dqslab,
-                           bf16* dkv, bf16* dkvT, const EncDims& D, hipStream_t st, DropCfg drop = no_drop()) {
-    dim3 grid(D.nkb, D.B * D.h);
-    ProfScope prof(S_ATTN_BWD, st);
-    if (DKP == 16)
-        hipLaunchKernelGGL((attn_bwd_kernel<16, KT_BWD>), grid, dim3(MMT_THREADS), 0, st, QR, QT, KR, KT_, VR, dOR, dOT, lse, delta,
-                           dqslab, dkv, D.L.NQ, dkvT, D.MP, D.h, D.T, D.nt, D.M, D.L.HDP, drop);
-    else
-        hipLaunchKernelGGL((attn_bwd_kernel<32, KT_BWD>), grid, dim3(MMT_THREADS), 0, st, QR, QT, KR, KT_, VR, dOR, dOT, lse, delta,
-                           dqslab, dkv, D.L.NQ, dkvT, D.MP, D.h, D.T, D.nt, D.M, D.L.HDP, drop);
-    LAUNCH_CHECK("attn_bwd_kernel");
+                           const bf16* dOR, const bf16* dOT, const float* lse, const float* delta, const float* rowmask,
+                           bf16* dqkv, bf16* dqkvT, const EncDims& D, hipStream_t st, DropCfg drop = no_drop()) {
+    dim3 grid((D.nt + 3) / 4, D.B * D.h);
+    const float scale = 1.0f / sqrtf((float)D.L.dk);
+    {
+        ProfScope prof(S_ATTN_BWD, st);
+#define MMT_DKV(dkp, dr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, QT, KR, VR, dOR, dOT, lse, delta, \
+                                            dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, drop)
+        if (DKP == 16) { if (drop.thr16) MMT_DKV(16, true); else MMT_DKV(16, false); }
+        else { if (drop.thr16) MMT_DKV(32, true); else MMT_DKV(32, false); }
+#undef MMT_DKV
+    }
+    LAUNCH_CHECK("attn_bwd_dkv_kernel");
+    {
+        ProfScope prof(S_DQ_FINISH, st);
+#define MMT_DQ(dkp, dr) hipLaunchKernelGGL((attn_bwd_dq_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, KT_, VR, dOR, lse, delta, rowmask, \
+                                           scale, dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, drop)
+        if (DKP == 16) { if (drop.thr16) MMT_DQ(16, true); else MMT_DQ(16, false); }
+        else { if (drop.thr16) MMT_DQ(32, true); else MMT_DQ(32, false); }
+#undef MMT_DQ
+    }
+    LAUNCH_CHECK("attn_bwd_dq_kernel");
     return MMT_OK;
 }
 
@@ -393,14 +408,8 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             p.ctx = w.ctx; p.ldctx = L.HDP; p.delta = W.delta;
             if ((rc = launch_rowgemm<EPI_FRAG, false>(p, st, S_BWD_OUTPROJ))) return rc;
         }
-        if ((rc = launch_attn_bwd(L.DKP, w.QR, w.QT, w.KR, w.KT, w.VR, W.dOR, W.dOT, w.lse, W.delta, W.dqslab,
+        if ((rc = launch_attn_bwd(L.DKP, w.QR, w.QT, w.KR, w.KT, w.VR, W.dOR, W.dOT, w.lse, W.delta, mask,
                                   W.dqkv, W.dqkvT, D, st, make_drop(dropout_p, seed, 4 * l + 0)))) return rc;
-        {
-            ProfScope prof(S_DQ_FINISH, st);
-            hipLaunchKernelGGL(dq_finish_kernel, dim3(grid_for((size_t)D.M * L.HD / 4)), dim3(256), 0, st,
-                               W.dqslab, D.nkb, mask, 1.0f / sqrtf((float)L.dk), W.dqkv, L.NQ, W.dqkvT, D.MP, D.M, L.HD, L.HDP);
-        }
-        LAUNCH_CHECK("dq_finish_kernel");
         float* dxin = (l > 0) ? cur : dx;
         {   // dx = dx1 + LN1bwd(dQKV Wqkv)
             RowGemmParams p = rg_zero();
@@ -510,7 +519,7 @@ __global__ void unpad_heads_kernel(const bf16* __restrict__ src, int ld, int col
     }
 }
 
-struct SdpaWs { bf16 *QR, *QT, *KR, *KT, *VR, *VT, *dOR, *dOT, *ctx, *ctxT, *dqkv, *dqkvT; float *lse, *delta, *dqslab; size_t bytes; };
+struct SdpaWs { bf16 *QR, *QT, *KR, *KT, *VR, *VT, *dOR, *dOT, *ctx, *ctxT, *dqkv, *dqkvT; float *lse, *delta; size_t bytes; };
 static void carve_sdpa(SdpaWs& W, const EncDims& D, void* base) {
     Carver c(base);
     const LayerLayout& L = D.L;
@@ -521,7 +530,6 @@ static void carve_sdpa(SdpaWs& W, const EncDims& D, void* base) {
     W.ctx = c.take<bf16>(M * L.HDP); W.ctxT = c.take<bf16>((size_t)L.HDP * D.MP);
     W.dqkv = c.take<bf16>(M * L.NQ); W.dqkvT = c.take<bf16>((size_t)L.NQ * D.MP);
     W.lse = c.take<float>(BH * D.Tp); W.delta = c.take<float>(BH * D.Tp);
-    W.dqslab = c.take<float>((size_t)D.nkb * M * L.HDP);
     W.bytes = c.off;
 }
 
@@ -567,12 +575,7 @@ extern "C" int mmt_sdpa_backward(const float* dctx, const float* mask, float* dq
     hipLaunchKernelGGL(pack_frag_kernel, dim3(grid_for((size_t)D.M * h)), dim3(256), 0, st, dctx, W.dOR, W.dOT, nullptr, 1.f, 0,
                        W.ctx, L.HDP, W.delta, D.M, T, D.Tp, h, L.dk, L.DKP, d);
     LAUNCH_CHECK("pack_frag_kernel");
-    if ((rc = launch_attn_bwd(L.DKP, W.QR, W.QT, W.KR, W.KT, W.VR, W.dOR, W.dOT, W.lse, W.delta, W.dqslab, W.dqkv, W.dqkvT, D, st))) return rc;
-    // the pack above stored Q' = q*log2e/sqrt(dk); gradient wrt the caller's q needs the same factor folded as in
-    // the fused path: dq = (dS K)/sqrt(dk); a NULL mask blanks nothing
-    hipLaunchKernelGGL(dq_finish_kernel, dim3(grid_for((size_t)D.M * L.HD / 4)), dim3(256), 0, st, W.dqslab, D.nkb,
-                       mask, 1.0f / sqrtf((float)L.dk), W.dqkv, L.NQ, W.dqkvT, D.MP, D.M, L.HD, L.HDP);
-    LAUNCH_CHECK("dq_finish_kernel");
+    if ((rc = launch_attn_bwd(L.DKP, W.QR, W.QT, W.KR, W.KT, W.VR, W.dOR, W.dOT, W.lse, W.delta, mask, W.dqkv, W.dqkvT, D, st))) return rc;
     const int g = grid_for((size_t)D.M * d);
     hipLaunchKernelGGL(unpad_heads_kernel, dim3(g), dim3(256), 0, st, W.dqkv, L.NQ, 0, dq, D.M, h, L.dk, L.DKP, d);
     hipLaunchKernelGGL(unpad_heads_kernel, dim3(g), dim3(256), 0, st, W.dqkv, L.NQ, L.HD, dk, D.M, h, L.dk, L.DKP, d);
@@ -665,7 +668,7 @@ extern "C" int mmt_linear_forward(const float* x, const float* Wt, const float* 
     p.M = M; p.K = K; p.KP = W.KP; p.N = N; p.NP = W.NP;
     p.A = x; p.lda = K; p.W = W.Wp; p.bias = W.bp; p.act = act; p.rowscale = rowscale;
     p.out_f32 = y; p.ldo = N;
-    return launch_rowgemm<EPI_PLAIN, false>(p, st);
+    return launch_rowgemm<EPI_PLAIN, false>(p, st, S_LINEAR_FWD);
 }
 
 extern "C" int mmt_linear_backward(const float* dy, const float* x, const float* Wt, const float* y, const float* rowscale,
@@ -686,7 +689,7 @@ extern "C" int mmt_linear_backward(const float* dy, const float* x, const float*
         p.M = M; p.K = W.NP; p.KP = W.NP; p.N = K; p.NP = W.KP;
         p.A = W.g; p.a_bf16 = 1; p.lda = W.NP; p.W = W.WTp;
         p.out_f32 = dx; p.ldo = K;
-        if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st))) return rc;
+        if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st, S_LINEAR_BWD_DX))) return rc;
     }
     if (dW || db) {
         hipLaunchKernelGGL(transpose_cast_kernel, dim3((M + 31) / 32, W.KP / 32), dim3(256), 0, st, x, W.xT, M, K, W.KP, W.MP);
@@ -695,7 +698,10 @@ extern "C" int mmt_linear_backward(const float* dy, const float* x, const float*
         J.njobs = 1; J.MP = W.MP; J.M16 = W.M16; J.mchunk = W.mchunk;
         J.j[0].At = W.gT; J.j[0].Bt = W.xT; J.j[0].out = W.sW; J.j[0].bias_out = W.sb;
         J.j[0].NPj = W.NP; J.j[0].KPj = W.KP; J.j[0].tile0 = 0; J.j[0].tiles_k = W.KP / 64;
-        hipLaunchKernelGGL(wgrad_kernel, dim3((W.NP / 64) * (W.KP / 64), W.nsplit), dim3(MMT_THREADS), 0, st, J);
+        {
+            ProfScope prof(S_LINEAR_WGRAD, st);
+            hipLaunchKernelGGL(wgrad_kernel, dim3((W.NP / 64) * (W.KP / 64), W.nsplit), dim3(MMT_THREADS), 0, st, J);
+        }
         LAUNCH_CHECK("wgrad_kernel");
         if (dW) hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for((size_t)N * K)), dim3(256), 0, st, W.sW, W.nsplit, W.NP, W.KP, dW, N, K);
         if (db) hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for((size_t)N)), dim3(256), 0, st, W.sb, W.nsplit, 1, W.NP, db, 1, N);
@@ -736,6 +742,7 @@ extern "C" int mmt_lstm_scan_forward(const float* gx, const float* W_rec, const 
     LAUNCH_CHECK("lstm_prep_kernel");
     const dim3 grid((B + 15) / 16), block(64 * (W.HP16 / 16));
     const size_t lds = (size_t)2 * 16 * (W.KP + 8) * 2;
+    ProfScope prof(S_LSTM_FWD, st);
     if (W.HP16 <= 64) hipLaunchKernelGGL((lstm_scan_fwd_kernel<2, 256, true>), grid, block, lds, st, gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, W.KP);
     else if (W.HP16 <= 128) hipLaunchKernelGGL((lstm_scan_fwd_kernel<4, 512, true>), grid, block, lds, st, gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, W.KP);
     else hipLaunchKernelGGL((lstm_scan_fwd_kernel<8, 1024, false>), grid, block, lds, st, gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, W.KP);
@@ -758,6 +765,7 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
     const size_t lds = (size_t)2 * 16 * (W.KP4 + 8) * 2;
     static bool attr = false;
     if (!attr) { if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false>))) return rc; attr = true; }
+    ProfScope prof(S_LSTM_BWD, st);
     if (W.HP16 <= 64) hipLaunchKernelGGL((lstm_scan_bwd_kernel<8, 256, true>), grid, block, lds, st, dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, W.KP4);
     else if (W.HP16 <= 128) hipLaunchKernelGGL((lstm_scan_bwd_kernel<16, 512, true>), grid, block, lds, st, dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, W.KP4);
     else hipLaunchKernelGGL((lstm_scan_bwd_kernel<32, 1024, false>), grid, block, lds, st, dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, W.KP4);
@@ -793,6 +801,7 @@ extern "C" int mmt_mfn_mem_scan_forward(const float* apre, const float* chat, co
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(mfn_prep_kernel, dim3(64), dim3(256), 0, st, Wm, W2, W.WmF, W.W2F, W.WmB, W.W2B);
     LAUNCH_CHECK("mfn_prep_kernel");
+    ProfScope prof(S_MEM_FWD, st);
     hipLaunchKernelGGL(mfn_mem_scan_fwd_kernel, dim3((B + 15) / 16), dim3(512), 0, st, apre, chat, W.WmF, W.W2F, b2, mem_all, u_all, g_all, T, B,
                        make_drop(dropout_p, seed, 1000));
     LAUNCH_CHECK("mfn_mem_scan_fwd_kernel");
@@ -812,6 +821,7 @@ extern "C" int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* cha
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(mfn_prep_kernel, dim3(64), dim3(256), 0, st, Wm, W2, W.WmF, W.W2F, W.WmB, W.W2B);
     LAUNCH_CHECK("mfn_prep_kernel");
+    ProfScope prof(S_MEM_BWD, st);
     hipLaunchKernelGGL(mfn_mem_scan_bwd_kernel, dim3((B + 15) / 16), dim3(512), 0, st, dmem_all, chat, mem_all, u_all, g_all, W.WmB, W.W2B,
                        dchat, dapre, dz_all, T, B, make_drop(dropout_p, 0, 0).scale);
     LAUNCH_CHECK("mfn_mem_scan_bwd_kernel");
@@ -822,16 +832,23 @@ extern "C" int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* cha
 // ------------------------------------------------------------------------------------ test hook
 // keep[i] = 1 if index i of dropout stream `stream` is kept under (p, seed): lets a test rebuild the exact masks the
 // kernels used and replay the reference arithmetic with them.
-__global__ void dropout_mask_kernel(DropCfg c, uint64_t n, uint8_t* __restrict__ keep) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        keep[i] = drop_keep(c, i) ? 1 : 0;
+// attn_Tp == 0: flat stream (index i).  attn_Tp > 0: attention-probability stream, i = (bh*Tp + q)*Tp + key, which the
+// attention kernels evaluate as a per-(batch,head) stream with the 32-bit index q*Tp + key.
+__global__ void dropout_mask_kernel(DropCfg c, uint64_t n, uint32_t attn_Tp, uint8_t* __restrict__ keep) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (attn_Tp == 0) { keep[i] = drop_keep(c, i) ? 1 : 0; continue; }
+        const uint64_t per = (uint64_t)attn_Tp * attn_Tp;
+        const uint32_t bh = (uint32_t)(i / per), idx = (uint32_t)(i - (uint64_t)bh * per);
+        const uint32_t w = drop_word(c.s0 + bh * 0x7F4A7C15u, c.s1, idx >> 1);
+        keep[i] = (((idx & 1) ? (w >> 16) : (w & 0xFFFFu)) >= c.thr16) ? 1 : 0;
+    }
 }
-extern "C" int mmt_debug_dropout_mask(float p, uint64_t seed, uint32_t stream_id, uint64_t n, uint8_t* keep, float* scale_out,
-                                      mmt_stream_t stream) {
+extern "C" int mmt_debug_dropout_mask(float p, uint64_t seed, uint32_t stream_id, uint64_t n, uint32_t attn_Tp, uint8_t* keep,
+                                      float* scale_out, mmt_stream_t stream) {
     if (!keep) return fail(MMT_EINVAL, "null pointer argument");
     const DropCfg c = make_drop(p, seed, stream_id);
     if (scale_out) *scale_out = c.scale;        // host pointer
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), c, n, keep);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), c, n, attn_Tp, keep);
     LAUNCH_CHECK("dropout_mask_kernel");
     return MMT_OK;
 }

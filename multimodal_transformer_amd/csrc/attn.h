@@ -13,78 +13,120 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
-// Forward.  grid = (ceil(nt/4), B*h), 4 waves; wave w owns query tile qt = 4*blockIdx.x + w (32 queries,
-// one per lane column: S^T = K Q'^T puts the query on the lane, so running max / sum / rescale are
-// lane-local and the only cross-lane step is one exchange between the two 32-lane halves).
-// P^T (accumulator: keys in registers) is fed straight back as the B operand of O^T += V^T P^T.
-template <int DKP>
+// All three kernels below are barrier-free and LDS-free: grid = (ceil(nt/4), B*h), 4 independent waves per
+// workgroup, each owning one 32-window tile and sweeping the other axis, with the next tile's operand
+// fragments already in flight (register prefetch) while the current one computes.  Register budgets stay
+// near 100 VGPRs so 4-5 waves share a SIMD and hide each other's MFMA / exp latencies.
+
+// per-(batch,head) dropout stream on the probabilities: 32-bit index q*Tp + key, one hash word per key pair
+__device__ __forceinline__ void drop_probs_qlane(f32x16& v, const DropCfg& dc, uint32_t base, int hh) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {       // registers (i, i+1) hold adjacent keys
+        const uint32_t w = drop_word(dc.s0, dc.s1, (base + (uint32_t)acc32_row(i, hh)) >> 1);
+        v[i] = drop_lo(dc, w, v[i]); v[i + 1] = drop_hi(dc, w, v[i + 1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward.  S^T = K Q'^T puts the query on the lane column: running max / sum / rescale are lane-local and
+// the only cross-lane step is one exchange between the two 32-lane halves.  After the first key tile the
+// running max m is preloaded as the accumulator (S' = S - m straight out of the MFMA) and the state is only
+// rescaled when some row's tile maximum exceeds m by more than RESCALE_THR (then P <= 2^THR, harmless in
+// bf16/fp32): the common path per score is max3 + exp + convert.  P^T (keys in registers) is fed straight
+// back as the B operand of O^T += V^T P^T.  For DKP == 16 the idle half of that MFMA also forms the row sums
+// (row 16 of V^T is synthesised as ones) unless dropout is on (the normaliser uses the undropped P).
+#define MMT_RESCALE_THR 8.0f
+
+template <int DKP, bool DROP>
 __global__ __launch_bounds__(MMT_THREADS) void attn_fwd_kernel(
         const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vt,
         bf16* __restrict__ ctx, bf16* __restrict__ ctxT, float* __restrict__ lse,
         int h, int T, int nt, int ldc, int MP, DropCfg drop) {
-    constexpr int KS = DKP / 16;                       // k-steps over the head feature
+    constexpr int KS = DKP / 16;
+    constexpr bool ONES = (DKP == 16) && !DROP;        // row sums through the MFMA
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int qt = blockIdx.x * 4 + wave;
-    if (qt >= nt) return;                              // no barriers in this kernel
+    if (qt >= nt) return;
     const int bh = blockIdx.y, b = bh / h, head = bh - b * h;
     const int Tp = nt * 32;
     const bf16* Qb = Qr + (size_t)bh * fragR_elems(Tp, DKP);
     const bf16* Kb = Kr + (size_t)bh * fragR_elems(Tp, DKP);
     const bf16* Vb = Vt + (size_t)bh * fragT_elems(Tp);
+    DropCfg dc = drop;
+    dc.s0 += (uint32_t)bh * 0x7F4A7C15u;
 
-    bf16x8 qf[KS];
+    bf16x8 qf[KS], kf[KS], vf[2], kn[KS], vn[2];
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
+    for (int s = 0; s < KS; ++s) {
         qf[s] = *reinterpret_cast<const bf16x8*>(Qb + ((size_t)(qt * (DKP / 8) + 2 * s + hh) * 32 + r) * 8);
+        kf[s] = *reinterpret_cast<const bf16x8*>(Kb + ((size_t)(2 * s + hh) * 32 + r) * 8);
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) vf[s2] = *reinterpret_cast<const bf16x8*>(Vb + ((size_t)(s2 * 2 + hh) * 32 + r) * 8);
 
     f32x16 o;
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = 0.f;
-    float mrun = -INFINITY, lrun = 0.f;
+    float mrun = 0.f, lrun = 0.f;
 
     for (int kt = 0; kt < nt; ++kt) {
-        f32x16 s;
+        if (kt + 1 < nt) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+            for (int s = 0; s < KS; ++s)
+                kn[s] = *reinterpret_cast<const bf16x8*>(Kb + ((size_t)((kt + 1) * (DKP / 8) + 2 * s + hh) * 32 + r) * 8);
 #pragma unroll
-        for (int ss = 0; ss < KS; ++ss) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Kb + ((size_t)(kt * (DKP / 8) + 2 * ss + hh) * 32 + r) * 8);
-            s = mfma32(kf, qf[ss], s);
+            for (int s2 = 0; s2 < 2; ++s2)
+                vn[s2] = *reinterpret_cast<const bf16x8*>(Vb + ((size_t)(((kt + 1) * 2 + s2) * 2 + hh) * 32 + r) * 8);
         }
+        f32x16 s;
+        const float init = (kt == 0) ? 0.f : -mrun;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = init;
+#pragma unroll
+        for (int ss = 0; ss < KS; ++ss) s = mfma32(kf[ss], qf[ss], s);
         if (kt == nt - 1 && (T & 31)) {                // keys >= T do not exist
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 if (kt * 32 + acc32_row(i, hh) >= T) s[i] = -INFINITY;
         }
-        float tmax = s[0];
+        float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
-        for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float mnew = fmaxf(mrun, tmax);          // finite: every tile holds >= 1 real key for hh = 0 or 1
-        const float alpha = fast_exp2(mrun - mnew);
+        for (int i = 3; i < 15; i += 2) tmax = fmaxf(fmaxf(tmax, s[i]), s[i + 1]);
+        tmax = fmaxf(tmax, s[15]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));      // finite: every tile holds >= 1 real key in one of the halves
+        if (kt == 0 || __any(tmax > MMT_RESCALE_THR)) {
+            // move the reference to the new running max (first tile: from 0 to the tile max, with o = l = 0)
+            const float dlt = (kt == 0) ? tmax : fmaxf(tmax, 0.f);
+            const float alpha = fast_exp2(-dlt);
+            mrun += dlt;
+            lrun *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o[i] *= alpha; s[i] -= dlt; }
+        }
         float psum = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { s[i] = fast_exp2(s[i] - mnew); psum += s[i]; }
-        lrun = lrun * alpha + psum;
-        mrun = mnew;
-        if (drop.thr16) {      // dropout on the probabilities (reference :32-33); the normaliser keeps the undropped sum
-            const uint64_t base = ((uint64_t)bh * Tp + (uint64_t)(qt * 32 + r)) * Tp + (uint64_t)kt * 32;
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) {     // keys of registers (i, i+1) are adjacent: one hash word per pair
-                const uint32_t w = drop_pair(drop, base + acc32_row(i, hh));
-                s[i] = drop_lo(drop, w, s[i]); s[i + 1] = drop_hi(drop, w, s[i + 1]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[i] *= alpha;
+        for (int i = 0; i < 16; ++i) { s[i] = fast_exp2(s[i]); if (!ONES) psum += s[i]; }
+        if (!ONES) lrun += psum;
+        if (DROP) drop_probs_qlane(s, dc, (uint32_t)(qt * 32 + r) * (uint32_t)Tp + (uint32_t)(kt * 32), hh);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vb + ((size_t)((kt * 2 + s2) * 2 + hh) * 32 + r) * 8);
-            o = mfma32(vf, pack8(s, s2), o);
+            bf16x8 va = vf[s2];
+            if (ONES && r == DKP) va = ones;           // V^T rows >= DKP are zero in memory; row DKP becomes the ones row
+            o = mfma32(va, pack8(s, s2), o);
+        }
+        if (kt + 1 < nt) {
+#pragma unroll
+            for (int ss = 0; ss < KS; ++ss) kf[ss] = kn[ss];
+            vf[0] = vn[0]; vf[1] = vn[1];
         }
     }
-    const float ltot = lrun + __shfl_xor(lrun, 32);
+    float ltot;
+    if (ONES) ltot = __shfl(o[8], r);                  // O^T row 16 = (register 8, lower half): the row sums
+    else ltot = lrun + __shfl_xor(lrun, 32);
     const float inv = 1.0f / ltot;
     const int t = qt * 32 + r;
     if (t < T) {
@@ -105,60 +147,47 @@ __global__ __launch_bounds__(MMT_THREADS) void attn_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward.  grid = (nkb, B*h), 4 waves; wave w owns KT key tiles (32 keys each, the key on the lane
-// column), so a workgroup covers 128*KT keys and keeps dK^T, dV^T for them in accumulators while it
-// sweeps all query tiles: no cross-workgroup sum for dK/dV.  Per (query tile, key tile):
-//     S'  = Q' K^T - L      (L preloaded as the accumulator: P = 2^S' needs no subtraction)
+// Backward, part A: dK, dV.  Wave w owns key tile kt = 4*blockIdx.x + w (the key on the lane column) and
+// sweeps all query tiles, keeping dK^T, dV^T in accumulators.  Per query tile:
+//     S'  = Q' K^T - L      (L preloaded as the accumulator rows: P = 2^S' needs no subtraction)
 //     dPc = dO V^T - delta  (same trick with delta = rowsum(dO . O))
-//     dS  = P * dPc ;  dV^T += dO^T P ;  dK^T += Q'^T dS     (P, dS accumulators are the B operands)
-// dS crosses LDS once (bf16, already in MFMA k-order) and ONE wave per query tile (rotating) forms
-// dQ = dS K for all the workgroup's keys, so dQ needs no cross-wave sum either; across key blocks it is
-// written to per-block fp32 slabs [nkb][M][HDP] that dq_finish_kernel adds (deterministic, no atomics).
-template <int DKP, int KT>
-__global__ __launch_bounds__(MMT_THREADS) void attn_bwd_kernel(
-        const bf16* __restrict__ Qr, const bf16* __restrict__ Qt,
-        const bf16* __restrict__ Kr, const bf16* __restrict__ Kt,
-        const bf16* __restrict__ Vr,
+//     dS  = P * dPc ;  dV^T += dO^T P ;  dK^T += Q'^T dS     (P, dS accumulators ARE the B operands)
+template <int DKP, bool DROP>
+__global__ __launch_bounds__(MMT_THREADS) void attn_bwd_dkv_kernel(
+        const bf16* __restrict__ Qr, const bf16* __restrict__ Qt, const bf16* __restrict__ Kr, const bf16* __restrict__ Vr,
         const bf16* __restrict__ dOr, const bf16* __restrict__ dOt,
         const float* __restrict__ lse, const float* __restrict__ delta,
-        float* __restrict__ dq_slab,            // [nkb][M][ldq]
         bf16* __restrict__ dkv, int lddkv,      // row-major [M][lddkv]; dK at column HD, dV at 2*HD
         bf16* __restrict__ dkvT, int MP,        // T layout  [3*HD rows][MP]
-        int h, int T, int nt, int M, int ldq, DropCfg drop) {
+        int h, int T, int nt, DropCfg drop) {
     constexpr int KS = DKP / 16;
-    constexpr int KB_TILES = 4 * KT;                   // key tiles per workgroup
-    constexpr int LDS_ROW = KB_TILES * 32 + 8;         // bf16 elements per dS row (+8: bank spread)
-    __shared__ __attribute__((aligned(16))) bf16 dS_lds[2][32 * LDS_ROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
+    const int kt = blockIdx.x * 4 + wave;
+    if (kt >= nt) return;
     const int bh = blockIdx.y, b = bh / h, head = bh - b * h;
-    const int kb = blockIdx.x;
     const int Tp = nt * 32, HD = h * DKP;
     const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
     const bf16 *Qrb = Qr + offR, *Krb = Kr + offR, *Vrb = Vr + offR, *dOrb = dOr + offR;
-    const bf16 *Qtb = Qt + offT, *Ktb = Kt + offT, *dOtb = dOt + offT;
+    const bf16 *Qtb = Qt + offT, *dOtb = dOt + offT;
     const float* lseb = lse + (size_t)bh * Tp;
     const float* delb = delta + (size_t)bh * Tp;
+    DropCfg dc = drop;
+    dc.s0 += (uint32_t)bh * 0x7F4A7C15u;
 
-    // this wave's key tiles; a tile index >= nt is an empty tile (no keys): its P is forced to 0
-    int ktile[KT];
-    bf16x8 kfr[KT][KS], vfr[KT][KS];
-    f32x16 dKacc[KT], dVacc[KT];
+    bf16x8 kfr[KS], vfr[KS];
 #pragma unroll
-    for (int i = 0; i < KT; ++i) {
-        ktile[i] = (kb * 4 + wave) * KT + i;
-        const int kt = ktile[i] < nt ? ktile[i] : nt - 1;     // clamp loads in bounds
-#pragma unroll
-        for (int ss = 0; ss < KS; ++ss) {
-            const size_t off = ((size_t)(kt * (DKP / 8) + 2 * ss + hh) * 32 + r) * 8;
-            kfr[i][ss] = *reinterpret_cast<const bf16x8*>(Krb + off);
-            vfr[i][ss] = *reinterpret_cast<const bf16x8*>(Vrb + off);
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { dKacc[i][j] = 0.f; dVacc[i][j] = 0.f; }
+    for (int ss = 0; ss < KS; ++ss) {
+        const size_t off = ((size_t)(kt * (DKP / 8) + 2 * ss + hh) * 32 + r) * 8;
+        kfr[ss] = *reinterpret_cast<const bf16x8*>(Krb + off);
+        vfr[ss] = *reinterpret_cast<const bf16x8*>(Vrb + off);
     }
-    // position of this lane's key inside a dS row segment of its tile (MFMA k-order, see fragT_index)
-    const int kpos = ((r >> 4) & 1) * 16 + ((r >> 2) & 1) * 8 + 4 * ((r >> 3) & 1) + (r & 3);
+    f32x16 dKacc, dVacc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { dKacc[j] = 0.f; dVacc[j] = 0.f; }
+    const bool key_tail = (kt == nt - 1) && (T & 31);
+    const bool key_ok = (kt * 32 + r) < T;
+    const uint32_t kcol = (uint32_t)(kt * 32 + r);
 
     for (int qt = 0; qt < nt; ++qt) {
         bf16x8 qa[KS], da[KS], qT[2], dT[2];
@@ -174,93 +203,59 @@ __global__ __launch_bounds__(MMT_THREADS) void attn_bwd_kernel(
             qT[s2] = *reinterpret_cast<const bf16x8*>(Qtb + off);
             dT[s2] = *reinterpret_cast<const bf16x8*>(dOtb + off);
         }
-        // row constants (rows = queries of this tile, 4 consecutive per register group)
-        f32x16 negL, negD;
+        f32x16 s, dp;                   // row constants (4 consecutive queries per register group) as the accumulators
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(lseb + qt * 32 + 8 * g + 4 * hh);
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(delb + qt * 32 + 8 * g + 4 * hh);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { negL[4 * g + i] = -l4[i]; negD[4 * g + i] = -d4[i]; }
+            for (int i = 0; i < 4; ++i) { s[4 * g + i] = -l4[i]; dp[4 * g + i] = -d4[i]; }
         }
-        bf16* dSw = dS_lds[qt & 1];
+        f32x16 negD;
+        if (DROP) negD = dp;
 #pragma unroll
-        for (int i = 0; i < KT; ++i) {
-            f32x16 s = negL, dp = negD;
+        for (int ss = 0; ss < KS; ++ss) { s = mfma32(qa[ss], kfr[ss], s); dp = mfma32(da[ss], vfr[ss], dp); }
 #pragma unroll
-            for (int ss = 0; ss < KS; ++ss) { s = mfma32(qa[ss], kfr[i][ss], s); dp = mfma32(da[ss], vfr[i][ss], dp); }
-            const bool key_ok = (ktile[i] * 32 + r) < T;
-            f32x16 ds;
+        for (int j = 0; j < 16; ++j) s[j] = fast_exp2(s[j]);
+        if (key_tail) {                                 // keys >= T do not exist
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s[j] = key_ok ? s[j] : 0.f;
+        }
+        if (qt == nt - 1 && (T & 31)) {                 // neither do queries >= T
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (qt * 32 + acc32_row(j, hh) >= T) s[j] = 0.f;
+        }
+        if (DROP) {
+            // dropped probabilities Pd = P*m/(1-p):  dV^T += dO^T Pd ;  dS = P * ((dO V^T)*m/(1-p) - delta); delta unchanged
+            const uint32_t q0 = (uint32_t)(qt * 32) * (uint32_t)Tp + kcol;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const bool ok = key_ok && (qt * 32 + acc32_row(j, hh) < T);
-                const float pv = ok ? fast_exp2(s[j]) : 0.f;
-                s[j] = pv;
-                ds[j] = pv * dp[j];
+                const uint32_t idx = q0 + (uint32_t)acc32_row(j, hh) * (uint32_t)Tp;
+                const uint32_t w = drop_word(dc.s0, dc.s1, idx >> 1);
+                const float ms = (((idx & 1) ? (w >> 16) : (w & 0xFFFFu)) >= dc.thr16) ? dc.scale : 0.f;
+                dp[j] = s[j] * ((dp[j] - negD[j]) * ms + negD[j]);
+                s[j] *= ms;
             }
-            if (drop.thr16) {
-                // with dropped probabilities Pd = P*m/(1-p):  dV^T += dO^T Pd ;  dS = P * ((dO V^T)*m/(1-p) - delta)
-                // (delta = rowsum(dO.O) is unchanged); dp holds dO V^T - delta, negD holds -delta.
-                const uint64_t kcol = (uint64_t)ktile[i] * 32 + r;
+        } else {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const uint64_t idx = ((uint64_t)bh * Tp + (uint64_t)(qt * 32 + acc32_row(j, hh))) * Tp + kcol;
-                    const float ms = drop_keep(drop, idx) ? drop.scale : 0.f;
-                    ds[j] = s[j] * ((dp[j] - negD[j]) * ms + negD[j]);
-                    s[j] *= ms;
-                }
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                dVacc[i] = mfma32(dT[s2], pack8(s, s2), dVacc[i]);
-                dKacc[i] = mfma32(qT[s2], pack8(ds, s2), dKacc[i]);
-            }
-            // dS -> LDS [query row][key position], keys of tile (wave, i) at segment (wave*KT + i)*32
-            const int seg = (wave * KT + i) * 32 + kpos;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) dSw[acc32_row(j, hh) * LDS_ROW + seg] = (bf16)ds[j];
+            for (int j = 0; j < 16; ++j) dp[j] *= s[j];
         }
-        __syncthreads();
-        if ((qt & 3) == wave) {
-            // dQ tile [32 queries][e] = sum over the workgroup's keys of dS K
-            f32x16 dq;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) dq[j] = 0.f;
-            for (int tl = 0; tl < KB_TILES; ++tl) {
-                const int kt_g = kb * KB_TILES + tl;
-                if (kt_g >= nt) break;
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(dSw + r * LDS_ROW + tl * 32 + s2 * 16 + hh * 8);
-                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(Ktb + ((size_t)((kt_g * 2 + s2) * 2 + hh) * 32 + r) * 8);
-                    dq = mfma32(af, bf, dq);
-                }
-            }
-            if (r < DKP) {
-                float* slab = dq_slab + (size_t)kb * M * ldq;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int t = qt * 32 + acc32_row(j, hh);
-                    if (t < T) slab[((size_t)b * T + t) * ldq + head * DKP + r] = dq[j];
-                }
-            }
+        for (int s2 = 0; s2 < 2; ++s2) {
+            dVacc = mfma32(dT[s2], pack8(s, s2), dVacc);
+            dKacc = mfma32(qT[s2], pack8(dp, s2), dKacc);
         }
-        // (the buffer written at tile qt is next written at qt+2, after the barrier of tile qt+1,
-        //  which the dQ wave only reaches once it has finished reading it)
     }
-
     // dK = ln2 * acc (scores are in the log2 domain), dV = acc; rows e = acc32_row, column key = r
     const float LN2 = 0.6931471805599453f;
-#pragma unroll
-    for (int i = 0; i < KT; ++i) {
-        const int t = ktile[i] * 32 + r;
-        if (ktile[i] >= nt || t >= T) continue;
+    const int t = kt * 32 + r;
+    if (t < T) {
         const size_t m = (size_t)b * T + t;
 #pragma unroll
         for (int g = 0; g < DKP / 8; ++g) {
             bf16x4 kv, vv;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { kv[j] = (bf16)(dKacc[i][4 * g + j] * LN2); vv[j] = (bf16)dVacc[i][4 * g + j]; }
+            for (int j = 0; j < 4; ++j) { kv[j] = (bf16)(dKacc[4 * g + j] * LN2); vv[j] = (bf16)dVacc[4 * g + j]; }
             const int e0 = head * DKP + 8 * g + 4 * hh;
             *reinterpret_cast<bf16x4*>(dkv + m * lddkv + HD + e0) = kv;
             *reinterpret_cast<bf16x4*>(dkv + m * lddkv + 2 * HD + e0) = vv;
@@ -273,22 +268,105 @@ __global__ __launch_bounds__(MMT_THREADS) void attn_bwd_kernel(
     }
 }
 
-// dQ = rowmask * scale * sum over key-block slabs  ->  bf16 row-major columns [0,HD) of dQKV and its T layout
-__global__ void dq_finish_kernel(const float* __restrict__ slab, int nkb, const float* __restrict__ rowmask,
-                                 float scale, bf16* __restrict__ dqkv, int ld, bf16* __restrict__ dqkvT, int MP,
-                                 int M, int HD, int ldq) {
-    const int hd4 = HD >> 2;
-    const size_t total = (size_t)M * hd4;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int m = (int)(idx / hd4), c = (int)(idx - (size_t)m * hd4) * 4;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < nkb; ++s) acc += *reinterpret_cast<const f32x4*>(slab + ((size_t)s * M + m) * ldq + c);
-        const float sc = (rowmask && rowmask[m] == 0.0f) ? 0.f : scale;   // blanked query rows pass no gradient to Q
-        bf16x4 o;
+// ------------------------------------------------------------------------------------------------
+// Backward, part B: dQ.  Same orientation as the forward (query on the lane): wave w owns query tile
+// qt = 4*blockIdx.x + w and sweeps all key tiles; L and delta are lane constants; the dS^T accumulator
+// (keys in registers) is the B operand of dQ^T += K^T dS^T.  The epilogue applies 1/sqrt(d_k) and the
+// query-row mask (blanked rows pass no gradient to Q) and writes columns [0,HD) of dQKV in both layouts.
+template <int DKP, bool DROP>
+__global__ __launch_bounds__(MMT_THREADS) void attn_bwd_dq_kernel(
+        const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Kt, const bf16* __restrict__ Vr,
+        const bf16* __restrict__ dOr, const float* __restrict__ lse, const float* __restrict__ delta,
+        const float* __restrict__ rowmask, float scale,
+        bf16* __restrict__ dqkv, int lddqkv, bf16* __restrict__ dqkvT, int MP,
+        int h, int T, int nt, DropCfg drop) {
+    constexpr int KS = DKP / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int qt = blockIdx.x * 4 + wave;
+    if (qt >= nt) return;
+    const int bh = blockIdx.y, b = bh / h, head = bh - b * h;
+    const int Tp = nt * 32;
+    const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
+    const bf16 *Qrb = Qr + offR, *Krb = Kr + offR, *Vrb = Vr + offR, *dOrb = dOr + offR, *Ktb = Kt + offT;
+    DropCfg dc = drop;
+    dc.s0 += (uint32_t)bh * 0x7F4A7C15u;
+
+    bf16x8 qf[KS], dof[KS], kf[KS], vf[KS], ktf[2], kn[KS], vn[KS], ktn[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (bf16)(acc[i] * sc);
-        *reinterpret_cast<bf16x4*>(dqkv + (size_t)m * ld + c) = o;
+    for (int ss = 0; ss < KS; ++ss) {
+        const size_t off = ((size_t)(qt * (DKP / 8) + 2 * ss + hh) * 32 + r) * 8;
+        qf[ss] = *reinterpret_cast<const bf16x8*>(Qrb + off);
+        dof[ss] = *reinterpret_cast<const bf16x8*>(dOrb + off);
+        const size_t off0 = ((size_t)(2 * ss + hh) * 32 + r) * 8;
+        kf[ss] = *reinterpret_cast<const bf16x8*>(Krb + off0);
+        vf[ss] = *reinterpret_cast<const bf16x8*>(Vrb + off0);
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dqkvT[(size_t)(c + i) * MP + m] = o[i];
+    for (int s2 = 0; s2 < 2; ++s2) ktf[s2] = *reinterpret_cast<const bf16x8*>(Ktb + ((size_t)(s2 * 2 + hh) * 32 + r) * 8);
+    const float negL = -lse[(size_t)bh * Tp + qt * 32 + r];
+    const float negD = -delta[(size_t)bh * Tp + qt * 32 + r];
+    f32x16 dq;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dq[j] = 0.f;
+
+    for (int kt = 0; kt < nt; ++kt) {
+        if (kt + 1 < nt) {
+#pragma unroll
+            for (int ss = 0; ss < KS; ++ss) {
+                const size_t off = ((size_t)((kt + 1) * (DKP / 8) + 2 * ss + hh) * 32 + r) * 8;
+                kn[ss] = *reinterpret_cast<const bf16x8*>(Krb + off);
+                vn[ss] = *reinterpret_cast<const bf16x8*>(Vrb + off);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                ktn[s2] = *reinterpret_cast<const bf16x8*>(Ktb + ((size_t)(((kt + 1) * 2 + s2) * 2 + hh) * 32 + r) * 8);
+        }
+        f32x16 s, dp;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s[j] = negL; dp[j] = negD; }
+#pragma unroll
+        for (int ss = 0; ss < KS; ++ss) { s = mfma32(kf[ss], qf[ss], s); dp = mfma32(vf[ss], dof[ss], dp); }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s[j] = fast_exp2(s[j]);
+        if (kt == nt - 1 && (T & 31)) {                 // keys >= T do not exist
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (kt * 32 + acc32_row(j, hh) >= T) s[j] = 0.f;
+        }
+        if (DROP) {
+            const uint32_t base = (uint32_t)(qt * 32 + r) * (uint32_t)Tp + (uint32_t)(kt * 32);
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) {
+                const uint32_t w = drop_word(dc.s0, dc.s1, (base + (uint32_t)acc32_row(j, hh)) >> 1);
+                const float m0 = ((w & 0xFFFFu) >= dc.thr16) ? dc.scale : 0.f, m1 = ((w >> 16) >= dc.thr16) ? dc.scale : 0.f;
+                dp[j] = s[j] * ((dp[j] - negD) * m0 + negD);
+                dp[j + 1] = s[j + 1] * ((dp[j + 1] - negD) * m1 + negD);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dp[j] *= s[j];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) dq = mfma32(ktf[s2], pack8(dp, s2), dq);
+        if (kt + 1 < nt) {
+#pragma unroll
+            for (int ss = 0; ss < KS; ++ss) { kf[ss] = kn[ss]; vf[ss] = vn[ss]; }
+            ktf[0] = ktn[0]; ktf[1] = ktn[1];
+        }
+    }
+    const int t = qt * 32 + r;
+    if (t < T) {
+        const size_t m = (size_t)b * T + t;
+        const float sc = (rowmask && rowmask[m] == 0.0f) ? 0.f : scale;     // blanked query rows pass no gradient to Q
+#pragma unroll
+        for (int g = 0; g < DKP / 8; ++g) {
+            bf16x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (bf16)(dq[4 * g + j] * sc);
+            const int e0 = head * DKP + 8 * g + 4 * hh;
+            *reinterpret_cast<bf16x4*>(dqkv + m * lddqkv + e0) = v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dqkvT[(size_t)(e0 + j) * MP + m] = v[j];
+        }
     }
 }

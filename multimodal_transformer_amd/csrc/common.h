@@ -46,12 +46,18 @@ __device__ __forceinline__ int acc32_row(int reg, int hh) { return (reg & 3) + 8
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 
-// pack 8 accumulator registers [8s .. 8s+7] into one bf16 operand fragment
+// pack 8 accumulator registers [8s .. 8s+7] into one bf16 operand fragment: four v_cvt_pk_bf16_f32 on the
+// register pairs (0,1),(2,3),... (written pair-wise: the element-wise form makes hipcc pair (1,2),(3,4),...
+// and repair the result with v_alignbit/v_perm)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
-    bf16x8 r;
+    u32x4_t r;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (bf16)v[8 * s + j];
-    return r;
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 p = {v[8 * s + 2 * j], v[8 * s + 2 * j + 1]};
+        r[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2));
+    }
+    return __builtin_bit_cast(bf16x8, r);
 }
 
 // ---- fragment layout index maps (element offsets inside one (batch,head) matrix) ----------------

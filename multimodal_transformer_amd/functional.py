@@ -313,12 +313,12 @@ def mfn_mem_scan(apre, chat, Wm, W2, b2, dropout_p=0.0, seed=0):
     return _MfnMemScanFn.apply(apre, chat, Wm, W2, b2, float(dropout_p), int(seed))
 
 
-def dropout_mask(p, seed, stream_id, n, device):
+def dropout_mask(p, seed, stream_id, n, device, attn_Tp=0):
     """Test hook: (keep mask as a bool tensor of n entries, scale of kept values) of one dropout stream."""
     import ctypes
     lib = _lib.load()
     keep = torch.empty(n, dtype=torch.uint8, device=device)
     sc = ctypes.c_float(0.0)
-    _lib.check(lib.mmt_debug_dropout_mask(float(p), int(seed), int(stream_id), int(n), _lib.ptr(keep),
+    _lib.check(lib.mmt_debug_dropout_mask(float(p), int(seed), int(stream_id), int(n), int(attn_Tp), _lib.ptr(keep),
                                           ctypes.cast(ctypes.pointer(sc), ctypes.c_void_p), _lib.stream_ptr()))
     return keep.bool(), float(sc.value)

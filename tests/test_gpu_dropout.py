@@ -31,7 +31,7 @@ def _masks(dev, p, seed, n_layers, B, T, d, h, f):
     M = B * T
     out = []
     for l in range(n_layers):
-        ka, sa = F.dropout_mask(p, seed, 4 * l + 0, B * h * Tp * Tp, dev)
+        ka, sa = F.dropout_mask(p, seed, 4 * l + 0, B * h * Tp * Tp, dev, attn_Tp=Tp)
         k0, s0 = F.dropout_mask(p, seed, 4 * l + 1, M * DP, dev)
         kf, sf = F.dropout_mask(p, seed, 4 * l + 2, M * FP, dev)
         k1, s1 = F.dropout_mask(p, seed, 4 * l + 3, M * DP, dev)
