@@ -111,26 +111,30 @@ static int make_dims(EncDims& D, int B, int T, int d, int h, int f, int N) {
     D.M = B * T; D.MP = round_up(D.M, 64); D.M16 = round_up(D.M, 16);
     D.Tp = round_up(T, 32); D.nt = D.Tp / 32; D.G = (D.M + 31) / 32;
     D.L = make_layout(d, f, h);
-    // weight-gradient split over windows: aim for >= 512 workgroups
+    // weight-gradient split over windows: ONE launch covers every layer; aim for >= 768 workgroups in it
     const LayerLayout& L = D.L;
-    const int tiles = (L.NQ / 64) * (L.DP / 64) + (L.DP / 64) * (L.HDP / 64) + 2 * (L.FP / 64) * (L.DP / 64);
-    int s = (512 + tiles - 1) / tiles; if (s < 1) s = 1; if (s > 32) s = 32;
-    D.mchunk = round_up((D.M16 + s - 1) / s, 16);
-    D.nsplit = (D.M16 + D.mchunk - 1) / D.mchunk;
+    const int tiles = ((L.NQ / 64) * (L.DP / 64) + (L.DP / 64) * (L.HDP / 64) + 2 * (L.FP / 64) * (L.DP / 64)) * (N > 0 ? N : 1);
+    int s = (768 + tiles - 1) / tiles; if (s < 1) s = 1; if (s > 32) s = 32;
+    D.mchunk = round_up((D.MP + s - 1) / s, 64);
+    D.nsplit = (D.MP + D.mchunk - 1) / D.mchunk;
     return MMT_OK;
 }
 
 struct LayerWs {
     float *xout, *x1, *stats1, *stats2, *lse;
     bf16 *xn1T, *xn2T, *QR, *KR, *VR, *QT, *KT, *VT, *ctx, *ctxT, *hid, *hidT;
+    // backward operands of the weight-gradient GEMMs, kept per layer so ONE batched launch forms every layer's dW
+    bf16 *dx2T, *dhT, *dx1T, *dqkvT;
+    float *lnpart1, *lnpart2;
 };
 struct EncWs {
     bf16* wprep; float* bprep; float* statsf;
     LayerWs lw[MAX_LAYERS];
     // backward scratch (shared by all layers; single stream)
-    float *dxa, *dxb, *delta, *lnpart1, *lnpart2;
-    bf16 *dx2T, *dh, *dhT, *dx1T, *dOR, *dOT, *dqkv, *dqkvT;
-    float *sWqkv, *sbqkv, *sWo, *sbo, *sW1, *sb1, *sW2, *sb2;
+    float *dxa, *dxb, *delta, *lnpartf;
+    bf16 *dh, *dOR, *dOT, *dqkv;
+    float *sWqkv, *sbqkv, *sWo, *sbo, *sW1, *sb1, *sW2, *sb2;   // slab sets of layer 0; layer l at + l * slab_stride
+    size_t slab_stride;
     size_t bytes;
 };
 
@@ -153,19 +157,29 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
         w.VT = c.take<bf16>(BH * fragT_elems(D.Tp));
         w.ctx = c.take<bf16>(M * L.HDP); w.ctxT = c.take<bf16>((size_t)L.HDP * MP);
         w.hid = c.take<bf16>(M * L.FP); w.hidT = c.take<bf16>((size_t)L.FP * MP);
+        w.dx2T = c.take<bf16>((size_t)L.DP * MP); w.dhT = c.take<bf16>((size_t)L.FP * MP);
+        w.dx1T = c.take<bf16>((size_t)L.DP * MP); w.dqkvT = c.take<bf16>((size_t)L.NQ * MP);
+    }
+    for (int l = 0; l < D.N; ++l) {        // contiguous [layer][2 norms][G][2][DP] so one launch reduces them all
+        W.lw[l].lnpart1 = c.take<float>((size_t)D.G * 2 * L.DP); W.lw[l].lnpart2 = c.take<float>((size_t)D.G * 2 * L.DP);
     }
     W.dxa = c.take<float>(M * D.d); W.dxb = c.take<float>(M * D.d);
     W.delta = c.take<float>(BH * D.Tp);
-    W.lnpart1 = c.take<float>((size_t)D.G * 2 * L.DP); W.lnpart2 = c.take<float>((size_t)D.G * 2 * L.DP);
-    W.dx2T = c.take<bf16>((size_t)L.DP * MP); W.dh = c.take<bf16>(M * L.FP); W.dhT = c.take<bf16>((size_t)L.FP * MP);
-    W.dx1T = c.take<bf16>((size_t)L.DP * MP);
+    W.lnpartf = c.take<float>((size_t)D.G * 2 * L.DP);
+    W.dh = c.take<bf16>(M * L.FP);
     W.dOR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); W.dOT = c.take<bf16>(BH * fragT_elems(D.Tp));
-    W.dqkv = c.take<bf16>(M * L.NQ); W.dqkvT = c.take<bf16>((size_t)L.NQ * MP);
+    W.dqkv = c.take<bf16>(M * L.NQ);
     const size_t S = D.nsplit;
-    W.sWqkv = c.take<float>(S * L.NQ * L.DP); W.sbqkv = c.take<float>(S * L.NQ);
-    W.sWo = c.take<float>(S * L.DP * L.HDP); W.sbo = c.take<float>(S * L.DP);
-    W.sW1 = c.take<float>(S * L.FP * L.DP); W.sb1 = c.take<float>(S * L.FP);
-    W.sW2 = c.take<float>(S * L.DP * L.FP); W.sb2 = c.take<float>(S * L.DP);
+    {   // one slab set per layer, identical sizes: layer l's set lives at + l * slab_stride floats
+        const size_t before = c.off;
+        W.sWqkv = c.take<float>(S * L.NQ * L.DP); W.sbqkv = c.take<float>(S * L.NQ);
+        W.sWo = c.take<float>(S * L.DP * L.HDP); W.sbo = c.take<float>(S * L.DP);
+        W.sW1 = c.take<float>(S * L.FP * L.DP); W.sb1 = c.take<float>(S * L.FP);
+        W.sW2 = c.take<float>(S * L.DP * L.FP); W.sb2 = c.take<float>(S * L.DP);
+        const size_t set_bytes = c.off - before;
+        W.slab_stride = set_bytes / sizeof(float);
+        for (int l = 1; l < D.N; ++l) c.take<char>(set_bytes);
+    }
     W.bytes = c.off;
 }
 
@@ -366,26 +380,39 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
     float* gPf = dparams + (size_t)D.N * L.stride();
     const float* x_last = (D.N > 0) ? W.lw[D.N - 1].xout : x;
     float* cur = (D.N > 0) ? W.dxa : dx;
-    if ((rc = launch_ln_bwd(dy, x_last, Pf, W.statsf, eps, cur, W.lnpart1, D.M, d, L.DP, st))) return rc;
-    hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 31) / 32, 2), dim3(1024), 0, st, W.lnpart1, D.G, L.DP, d, gPf, gPf + d);
+    if ((rc = launch_ln_bwd(dy, x_last, Pf, W.statsf, eps, cur, W.lnpartf, D.M, d, L.DP, st))) return rc;
+    {
+        ProfScope prof(S_FINALIZE, st);
+        hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 31) / 32, 2, 1), dim3(1024), 0, st, W.lnpartf, D.G, L.DP, d, gPf, gPf + d,
+                           (size_t)0, (size_t)0);
+    }
     LAUNCH_CHECK("ln_param_finalize_kernel");
+
+    WgradJobs J; memset(&J, 0, sizeof(J));
+    J.MP = D.MP; J.M16 = D.M16; J.mchunk = D.mchunk;
+    int t0 = 0;
+    auto add_job = [&](const bf16* At, const bf16* Bt, float* out, float* bout, int NPj, int KPj) {
+        WgradJob& j = J.j[J.njobs++];
+        j.At = At; j.Bt = Bt; j.out = out; j.bias_out = bout;
+        j.NPj = NPj; j.KPj = KPj; j.tile0 = t0; j.tiles_k = KPj / 64;
+        t0 += (NPj / 64) * (KPj / 64);
+    };
 
     float* other = W.dxb;
     for (int l = D.N - 1; l >= 0; --l) {
         const LayerWs& w = W.lw[l];
         const float* P = params + (size_t)l * L.stride();
-        float* gP = dparams + (size_t)l * L.stride();
         const bf16* wp = W.wprep + (size_t)l * L.pstride();
         const float* xin = (l > 0) ? W.lw[l - 1].xout : x;
         {   // dh = (dx2 W2) * relu'(hid)          [also emits dx2^T for dW2]
             RowGemmParams p = rg_zero();
             p.M = D.M; p.K = d; p.KP = L.DP; p.N = f; p.NP = L.FP;
-            p.A = cur; p.lda = d; p.At_out = W.dx2T; p.ldt = D.MP;
+            p.A = cur; p.lda = d; p.At_out = w.dx2T; p.ldt = D.MP;
             p.W = wp + L.pW2T();
             p.relu_mask = w.hid; p.ldm = L.FP;          // hid > 0  <=>  ReLU passed AND the unit was kept
             p.mask_scale = make_drop(dropout_p, seed, 4 * l + 2).scale;
             p.a_drop = make_drop(dropout_p, seed, 4 * l + 3);   // gradient of the dropped sublayer-1 output
-            p.out_bf16 = W.dh; p.ldo16 = L.FP; p.n_store16 = L.FP; p.out_T = W.dhT; p.ldoT = D.MP;
+            p.out_bf16 = W.dh; p.ldo16 = L.FP; p.n_store16 = L.FP; p.out_T = w.dhT; p.ldoT = D.MP;
             if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st, S_BWD_FFN2))) return rc;
         }
         {   // dx1 = dx2 + LN2bwd(dh W1)
@@ -394,13 +421,13 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             p.A = W.dh; p.a_bf16 = 1; p.lda = L.FP;
             p.W = wp + L.pW1T();
             p.x = w.x1; p.ldx = d; p.st = w.stats2; p.ln_a = P + L.oln(2); p.eps = eps; p.d_real = d;
-            p.dres = cur; p.lddres = d; p.out_f32 = other; p.ldo = d; p.colpart = W.lnpart2;
+            p.dres = cur; p.lddres = d; p.out_f32 = other; p.ldo = d; p.colpart = w.lnpart2;
             if ((rc = launch_rowgemm<EPI_LNBWD, false>(p, st, S_BWD_FFN1_LN2))) return rc;
         }
         {   // dO = dx1 Wo -> fragments + delta     [also emits dx1^T for dWo]
             RowGemmParams p = rg_zero();
             p.M = D.M; p.K = d; p.KP = L.DP; p.N = L.HD; p.NP = L.HDP;
-            p.A = other; p.lda = d; p.At_out = W.dx1T; p.ldt = D.MP;
+            p.A = other; p.lda = d; p.At_out = w.dx1T; p.ldt = D.MP;
             p.W = wp + L.pWoT();
             p.a_drop = make_drop(dropout_p, seed, 4 * l + 1);   // gradient of the dropped sublayer-0 output
             p.fragR[0] = W.dOR; p.fragT[0] = W.dOT;
@@ -409,7 +436,7 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             if ((rc = launch_rowgemm<EPI_FRAG, false>(p, st, S_BWD_OUTPROJ))) return rc;
         }
         if ((rc = launch_attn_bwd(L.DKP, w.QR, w.QT, w.KR, w.KT, w.VR, W.dOR, W.dOT, w.lse, W.delta, mask,
-                                  W.dqkv, W.dqkvT, D, st, make_drop(dropout_p, seed, 4 * l + 0)))) return rc;
+                                  W.dqkv, w.dqkvT, D, st, make_drop(dropout_p, seed, 4 * l + 0)))) return rc;
         float* dxin = (l > 0) ? cur : dx;
         {   // dx = dx1 + LN1bwd(dQKV Wqkv)
             RowGemmParams p = rg_zero();
@@ -417,41 +444,39 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             p.A = W.dqkv; p.a_bf16 = 1; p.lda = L.NQ;
             p.W = wp + L.pWqkvT();
             p.x = xin; p.ldx = d; p.st = w.stats1; p.ln_a = P + L.oln(0); p.eps = eps; p.d_real = d;
-            p.dres = other; p.lddres = d; p.out_f32 = dxin; p.ldo = d; p.colpart = W.lnpart1;
+            p.dres = other; p.lddres = d; p.out_f32 = dxin; p.ldo = d; p.colpart = w.lnpart1;
             if ((rc = launch_rowgemm<EPI_LNBWD, false>(p, st, S_BWD_QKV_LN1))) return rc;
         }
-        {   // weight gradients of the layer
-            WgradJobs J; memset(&J, 0, sizeof(J));
-            J.njobs = 4; J.MP = D.MP; J.M16 = D.M16; J.mchunk = D.mchunk;
-            int t0 = 0;
-            auto add = [&](int i, const bf16* At, const bf16* Bt, float* out, float* bout, int NPj, int KPj) {
-                J.j[i].At = At; J.j[i].Bt = Bt; J.j[i].out = out; J.j[i].bias_out = bout;
-                J.j[i].NPj = NPj; J.j[i].KPj = KPj; J.j[i].tile0 = t0; J.j[i].tiles_k = KPj / 64;
-                t0 += (NPj / 64) * (KPj / 64);
-            };
-            add(0, W.dqkvT, w.xn1T, W.sWqkv, W.sbqkv, L.NQ, L.DP);
-            add(1, W.dx1T, w.ctxT, W.sWo, W.sbo, L.DP, L.HDP);
-            add(2, W.dhT, w.xn2T, W.sW1, W.sb1, L.FP, L.DP);
-            add(3, W.dx2T, w.hidT, W.sW2, W.sb2, L.DP, L.FP);
-            {
-                ProfScope prof(S_WGRAD, st);
-                hipLaunchKernelGGL(wgrad_kernel, dim3(t0, D.nsplit), dim3(MMT_THREADS), 0, st, J);
-            }
-            LAUNCH_CHECK("wgrad_kernel");
-            ProfScope prof(S_FINALIZE, st);
-            LayerSlabs S;
-            S.dWqkv = W.sWqkv; S.dbqkv = W.sbqkv; S.dWo = W.sWo; S.dbo = W.sbo;
-            S.dW1 = W.sW1; S.db1 = W.sb1; S.dW2 = W.sW2; S.db2 = W.sb2;
-            S.ln1part = W.lnpart1; S.ln2part = W.lnpart2; S.nsplit = D.nsplit; S.G = D.G;
-            hipLaunchKernelGGL(encoder_finalize_kernel, dim3(grid_for(L.oln(0))), dim3(256), 0, st, S, L, gP);
-            LAUNCH_CHECK("encoder_finalize_kernel");
-            hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 31) / 32, 2), dim3(1024), 0, st, W.lnpart1, D.G, L.DP, d,
-                               gP + L.oln(0), gP + L.oln(1));
-            hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 31) / 32, 2), dim3(1024), 0, st, W.lnpart2, D.G, L.DP, d,
-                               gP + L.oln(2), gP + L.oln(3));
-            LAUNCH_CHECK("ln_param_finalize_kernel");
-        }
+        // weight-gradient jobs of this layer (run later, all layers in one launch)
+        const size_t so = (size_t)l * W.slab_stride;
+        add_job(w.dqkvT, w.xn1T, W.sWqkv + so, W.sbqkv + so, L.NQ, L.DP);
+        add_job(w.dx1T, w.ctxT, W.sWo + so, W.sbo + so, L.DP, L.HDP);
+        add_job(w.dhT, w.xn2T, W.sW1 + so, W.sb1 + so, L.FP, L.DP);
+        add_job(w.dx2T, w.hidT, W.sW2 + so, W.sb2 + so, L.DP, L.FP);
         // cur now holds dx of this layer (= dx2 of the layer below); `other` is free again
+    }
+    if (D.N > 0) {
+        {   // every layer's weight and bias gradients: one launch
+            ProfScope prof(S_WGRAD, st);
+            hipLaunchKernelGGL(wgrad_kernel, dim3(t0, D.nsplit), dim3(MMT_THREADS), 0, st, J);
+        }
+        LAUNCH_CHECK("wgrad_kernel");
+        ProfScope prof(S_FINALIZE, st);
+        LayerSlabs S;
+        S.dWqkv = W.sWqkv; S.dbqkv = W.sbqkv; S.dWo = W.sWo; S.dbo = W.sbo;
+        S.dW1 = W.sW1; S.db1 = W.sb1; S.dW2 = W.sW2; S.db2 = W.sb2;
+        S.ln1part = nullptr; S.ln2part = nullptr; S.nsplit = D.nsplit; S.G = D.G; S.slab_stride = W.slab_stride;
+        hipLaunchKernelGGL(encoder_finalize_kernel, dim3(grid_for(L.oln(0)), D.N), dim3(256), 0, st, S, L, dparams);
+        LAUNCH_CHECK("encoder_finalize_kernel");
+        // the 2N sublayer LayerNorms: partials are contiguous [layer][norm][G][2][DP]; outputs (a_2, b_2) pairs are 2d apart
+        // inside a layer block, so launch per norm index with the layer stride
+        const size_t pstride = (size_t)2 * D.G * 2 * L.DP;      // floats between layer l and l+1 for the same norm index
+        for (int k = 0; k < 2; ++k) {
+            float* oa = dparams + L.oln(2 * k);
+            hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 31) / 32, 2, D.N), dim3(1024), 0, st,
+                               k == 0 ? W.lw[0].lnpart1 : W.lw[0].lnpart2, D.G, L.DP, d, oa, oa + d, pstride, L.stride());
+        }
+        LAUNCH_CHECK("ln_param_finalize_kernel");
     }
     return MMT_OK;
 }
@@ -482,7 +507,7 @@ extern "C" int mmt_layernorm_backward(const float* dy, const float* x, const flo
     const int DP = round_up(d, 64), G = (M + 31) / 32;
     int rc = launch_ln_bwd(dy, x, a_2, stats, eps, dx, scratch, M, d, DP, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 31) / 32, 2), dim3(1024), 0, st, scratch, G, DP, d, da_2, db_2);
+    hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 31) / 32, 2, 1), dim3(1024), 0, st, scratch, G, DP, d, da_2, db_2, (size_t)0, (size_t)0);
     LAUNCH_CHECK("ln_param_finalize_kernel");
     return MMT_OK;
 }
@@ -632,8 +657,8 @@ static void carve_linear(LinWs& W, int M, int K, int N, void* base) {
     W.KP = round_up(K, 64); W.NP = round_up(N, 64); W.MP = round_up(M, 64); W.M16 = round_up(M, 16);
     const int tiles = (W.NP / 64) * (W.KP / 64);
     int s = (512 + tiles - 1) / tiles; if (s < 1) s = 1; if (s > 32) s = 32;
-    W.mchunk = round_up((W.M16 + s - 1) / s, 16);
-    W.nsplit = (W.M16 + W.mchunk - 1) / W.mchunk;
+    W.mchunk = round_up((W.MP + s - 1) / s, 64);
+    W.nsplit = (W.MP + W.mchunk - 1) / W.mchunk;
     W.Wp = c.take<bf16>((size_t)W.NP * W.KP); W.WTp = c.take<bf16>((size_t)W.KP * W.NP);
     W.bp = c.take<float>(W.NP);
     W.g = c.take<bf16>((size_t)M * W.NP); W.gT = c.take<bf16>((size_t)W.NP * W.MP); W.xT = c.take<bf16>((size_t)W.KP * W.MP);

@@ -222,52 +222,64 @@ struct WgradJob {
     const bf16* At; const bf16* Bt; float* out; float* bias_out;
     int NPj, KPj, tile0, tiles_k;
 };
-#define MMT_MAX_WGRAD_JOBS 8
+#define MMT_MAX_WGRAD_JOBS 64
 struct WgradJobs { WgradJob j[MMT_MAX_WGRAD_JOBS]; int njobs; int MP; int M16; int mchunk; };
 
 __global__ __launch_bounds__(MMT_THREADS) void wgrad_kernel(const WgradJobs jobs) {
+    // Operand tiles [64 features][64 windows] are fetched with full 128-byte lines (8 lanes x 16 B per feature row),
+    // the next chunk already in registers while the current one is multiplied out of LDS; rows are padded to 144 B so
+    // the 32-row x 16-byte fragment reads (ds_read_b128) are bank-conflict free.
+    constexpr int LDR = 72;                                    // bf16 elements per LDS row
+    __shared__ __attribute__((aligned(16))) bf16 As[2][64 * LDR];
+    __shared__ __attribute__((aligned(16))) bf16 Bs[2][64 * LDR];
     int ji = 0;
-#pragma unroll
-    for (int i = 1; i < MMT_MAX_WGRAD_JOBS; ++i) if (i < jobs.njobs && (int)blockIdx.x >= jobs.j[i].tile0) ji = i;
-    const WgradJob J = jobs.j[ji];
+    for (int i = 1; i < jobs.njobs; ++i) if ((int)blockIdx.x >= jobs.j[i].tile0) ji = i;
+    const WgradJob& J = jobs.j[ji];
     const int tile = blockIdx.x - J.tile0, tn = tile / J.tiles_k, tk = tile - tn * J.tiles_k;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
-    const int n0 = tn * 64 + (wave >> 1) * 32, k0 = tk * 64 + (wave & 1) * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int wn = wave >> 1, wk = wave & 1;
     const int split = blockIdx.y;
-    const int mbeg = split * jobs.mchunk, mend = min(jobs.M16, mbeg + jobs.mchunk);
-    const bf16* ap = J.At + (size_t)(n0 + r) * jobs.MP + 8 * hh;
-    const bf16* bp = J.Bt + (size_t)(k0 + r) * jobs.MP + 8 * hh;
-    const bool want_bias = (J.bias_out != nullptr) && tk == 0 && (wave & 1) == 0;
+    const int mbeg = split * jobs.mchunk, mend = min(jobs.MP, mbeg + jobs.mchunk);
+    // staging role of this thread: rows row0 and row0+32 of each tile, 16-byte segment seg
+    const int row0 = tid >> 3, seg = tid & 7;
+    const bf16* ag = J.At + (size_t)(tn * 64 + row0) * jobs.MP + seg * 8;
+    const bf16* bg = J.Bt + (size_t)(tk * 64 + row0) * jobs.MP + seg * 8;
+    const size_t half = (size_t)32 * jobs.MP;
+    const bool want_bias = (J.bias_out != nullptr) && tk == 0 && wk == 0;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float bsum = 0.f;
-    int m = mbeg;
-    for (; m + 64 <= mend; m += 64) {
-        bf16x8 a[4], b[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            a[u] = *reinterpret_cast<const bf16x8*>(ap + m + 16 * u);
-            b[u] = *reinterpret_cast<const bf16x8*>(bp + m + 16 * u);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc = mfma32(a[u], b[u], acc);
-            if (want_bias) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) bsum += (float)a[u][i];
+    if (mbeg < mend) {
+        bf16x8 ra0 = *reinterpret_cast<const bf16x8*>(ag + mbeg), ra1 = *reinterpret_cast<const bf16x8*>(ag + half + mbeg);
+        bf16x8 rb0 = *reinterpret_cast<const bf16x8*>(bg + mbeg), rb1 = *reinterpret_cast<const bf16x8*>(bg + half + mbeg);
+        int buf = 0;
+        for (int m = mbeg; m < mend; m += 64) {
+            *reinterpret_cast<bf16x8*>(&As[buf][row0 * LDR + seg * 8]) = ra0;
+            *reinterpret_cast<bf16x8*>(&As[buf][(row0 + 32) * LDR + seg * 8]) = ra1;
+            *reinterpret_cast<bf16x8*>(&Bs[buf][row0 * LDR + seg * 8]) = rb0;
+            *reinterpret_cast<bf16x8*>(&Bs[buf][(row0 + 32) * LDR + seg * 8]) = rb1;
+            __syncthreads();
+            if (m + 64 < mend) {                                // next chunk in flight behind this chunk's MFMAs
+                ra0 = *reinterpret_cast<const bf16x8*>(ag + m + 64); ra1 = *reinterpret_cast<const bf16x8*>(ag + half + m + 64);
+                rb0 = *reinterpret_cast<const bf16x8*>(bg + m + 64); rb1 = *reinterpret_cast<const bf16x8*>(bg + half + m + 64);
             }
-        }
-    }
-    for (; m < mend; m += 16) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + m);
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp + m);
-        acc = mfma32(a, b, acc);
-        if (want_bias) {
+            const bf16* ap = &As[buf][(wn * 32 + r) * LDR + 8 * hh];
+            const bf16* bp = &Bs[buf][(wk * 32 + r) * LDR + 8 * hh];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) bsum += (float)a[i];
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + ks * 16);
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp + ks * 16);
+                acc = mfma32(a, b, acc);
+                if (want_bias) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) bsum += (float)a[i];
+                }
+            }
+            buf ^= 1;       // the buffer written at chunk c is next written at chunk c+2, after the barrier of chunk c+1
         }
     }
+    const int n0 = tn * 64 + wn * 32, k0 = tk * 64 + wk * 32;
     float* out = J.out + (size_t)split * J.NPj * J.KPj;
 #pragma unroll
     for (int i = 0; i < 16; ++i) out[(size_t)(n0 + acc32_row(i, hh)) * J.KPj + k0 + r] = acc[i];
@@ -291,12 +303,18 @@ __global__ void slab_sum_kernel(const float* __restrict__ slab, int nsplit, int 
 
 // Encoder layer gradients -> flat fp32 gradient block of the layer (same layout as the parameters).
 struct LayerSlabs {
-    const float *dWqkv, *dbqkv, *dWo, *dbo, *dW1, *db1, *dW2, *db2;   // [nsplit][..]
+    const float *dWqkv, *dbqkv, *dWo, *dbo, *dW1, *db1, *dW2, *db2;   // layer 0: [nsplit][..]; layer l at + l * slab_stride
     const float *ln1part, *ln2part;                                    // [G][2][DP]
     int nsplit, G;
+    size_t slab_stride;                                                // floats between consecutive layers' slab sets
 };
 
-__global__ void encoder_finalize_kernel(LayerSlabs S, LayerLayout L, float* __restrict__ grad) {
+// grid = (blocks, n_layers): layer blockIdx.y's slabs -> its block of the flat gradient
+__global__ void encoder_finalize_kernel(LayerSlabs S0, LayerLayout L, float* __restrict__ grad0) {
+    LayerSlabs S = S0;
+    const size_t so = (size_t)blockIdx.y * S0.slab_stride;
+    S.dWqkv += so; S.dbqkv += so; S.dWo += so; S.dbo += so; S.dW1 += so; S.db1 += so; S.dW2 += so; S.db2 += so;
+    float* grad = grad0 + (size_t)blockIdx.y * L.stride();
     const int d = L.d, f = L.f;
     const size_t n_w = L.oln(0);                   // weights and biases of the layer
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_w; idx += (size_t)gridDim.x * blockDim.x) {
@@ -331,9 +349,14 @@ __global__ void encoder_finalize_kernel(LayerSlabs S, LayerLayout L, float* __re
 // LayerNorm parameter gradients: out_a[c] = sum_g part[g][1][c], out_b[c] = sum_g part[g][0][c].
 // grid = (DP/32, 2 {b,a}); 1024 threads = 32 columns x 32 row groups, coalesced 128-byte row reads,
 // fixed summation order (deterministic).
-__global__ __launch_bounds__(1024) void ln_param_finalize_kernel(const float* __restrict__ part, int G, int DP, int d,
-                                                                 float* __restrict__ out_a, float* __restrict__ out_b) {
+// blockIdx.z batches several LayerNorms: item z reads part + z*part_stride and writes out_a/out_b + z*out_stride
+__global__ __launch_bounds__(1024) void ln_param_finalize_kernel(const float* __restrict__ part0, int G, int DP, int d,
+                                                                 float* __restrict__ out_a0, float* __restrict__ out_b0,
+                                                                 size_t part_stride, size_t out_stride) {
     __shared__ float red[32][33];
+    const float* part = part0 + (size_t)blockIdx.z * part_stride;
+    float* out_a = out_a0 + (size_t)blockIdx.z * out_stride;
+    float* out_b = out_b0 + (size_t)blockIdx.z * out_stride;
     const int cx = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx, which = blockIdx.y;
     float s = 0.f;
