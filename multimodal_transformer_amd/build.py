@@ -22,9 +22,9 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # -amdgpu-mfma-vgpr-form: MFMA results in VGPRs (gfx950's file is unified): VALU consumers (exp, convert) read
-    # them directly instead of through v_accvgpr_read copies — the attention kernels are VALU-issue-bound
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form",
+    # NOTE: do NOT add `-mllvm -amdgpu-mfma-vgpr-form`: on ROCm 7.2 it deterministically miscompiles
+    # attn_bwd_dq_kernel<32,*> (27 % wrong dQ; same source is correct without it) — see DESIGN.md.
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wno-unused-result", "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)

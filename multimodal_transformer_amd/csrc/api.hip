@@ -276,6 +276,7 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
     if (rc) return rc;
     if (!x || !mask || !params || !y || !workspace) return fail(MMT_EINVAL, "null pointer argument");
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(MMT_EINVAL, "dropout_p %g not in [0,1)", dropout_p);
+    if (dropout_p > 0.f && D.Tp > 4096) return fail(MMT_EUNSUPPORTED, "train-mode dropout supports T <= 4096 (got %d)", T);
     EncWs W; carve_encoder(W, D, workspace);
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -531,7 +532,7 @@ __global__ void pack_frag_kernel(const float* __restrict__ src, bf16* __restrict
             ft[bh * fragT_elems(Tp) + fragT_index(t, e)] = v;
             if (delta) part += (float)v * (float)ctx[(size_t)m * ldctx + head * DKP + e];
         }
-        if (delta) delta[bh * Tp + t] = part;
+        if (delta) delta[bh * Tp + t] = -part;       // stored negated, like the fused path
     }
 }
 
@@ -864,7 +865,8 @@ __global__ void dropout_mask_kernel(DropCfg c, uint64_t n, uint32_t attn_Tp, uin
         if (attn_Tp == 0) { keep[i] = drop_keep(c, i) ? 1 : 0; continue; }
         const uint64_t per = (uint64_t)attn_Tp * attn_Tp;
         const uint32_t bh = (uint32_t)(i / per), idx = (uint32_t)(i - (uint64_t)bh * per);
-        const uint32_t w = drop_word(c.s0 + bh * 0x7F4A7C15u, c.s1, idx >> 1);
+        const DropCfg dc = drop_substream(c, bh);
+        const uint32_t w = drop_word_idx32(dc, idx);
         keep[i] = (((idx & 1) ? (w >> 16) : (w & 0xFFFFu)) >= c.thr16) ? 1 : 0;
     }
 }

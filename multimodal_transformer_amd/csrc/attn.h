@@ -10,19 +10,50 @@
 // Scores are kept in the log2 domain: the producer stores Q' = (x Wq^T + bq) * log2(e)/sqrt(d_k), so
 // P = 2^(S' - L) with L = rowmax + log2(rowsum) saved per query for the backward pass.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
-// All three kernels below are barrier-free and LDS-free: grid = (ceil(nt/4), B*h), 4 independent waves per
-// workgroup, each owning one 32-window tile and sweeping the other axis, with the next tile's operand
-// fragments already in flight (register prefetch) while the current one computes.  Register budgets stay
-// near 100 VGPRs so 4-5 waves share a SIMD and hide each other's MFMA / exp latencies.
+// All three kernels below: grid = (ceil(nt/4), B*h), 4 waves per workgroup, each wave owning one 32-window
+// tile of its own and sweeping the other axis.  The swept operand tile (K/V for the forward and dQ kernels,
+// Q/dO/L/delta for the dK-dV kernel) is the same for the four waves, so the workgroup stages it into LDS
+// cooperatively: 2-3 coalesced 16-byte loads per thread, issued one tile AHEAD into registers while the current
+// tile computes, written to the other half of a double buffer, one barrier per tile.  The LDS image keeps the
+// global fragment layouts (lane-linear 16-byte pieces), so every wave's MFMA operand is a conflict-free
+// ds_read_b128.  Register budgets stay near 100-130 VGPRs: 3-5 waves share a SIMD.
+template <int NSEG>
+struct TileStager {
+    // segment i: `pieces[i]` 16-byte pieces per tile, read from base[i] + tile * stride[i] (bf16 elements)
+    static constexpr int MAXL = 3;
+    const bf16* src[MAXL]; int stride[MAXL]; bool on[MAXL]; int lds_piece[MAXL];
+    bf16x8 reg[MAXL];
+    __device__ __forceinline__ void init(const bf16* const* base, const int* pieces, const int* strides, int tid) {
+#pragma unroll
+        for (int l = 0; l < MAXL; ++l) {
+            const int p = tid + MMT_THREADS * l;
+            int acc = 0; on[l] = false; src[l] = base[0]; stride[l] = 0; lds_piece[l] = p;
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) {
+                if (!on[l] && p >= acc && p < acc + pieces[sg]) { on[l] = true; src[l] = base[sg] + (size_t)(p - acc) * 8; stride[l] = strides[sg]; }
+                acc += pieces[sg];
+            }
+        }
+    }
+    __device__ __forceinline__ void load(int tile) {
+#pragma unroll
+        for (int l = 0; l < MAXL; ++l) if (on[l]) reg[l] = *reinterpret_cast<const bf16x8*>(src[l] + (size_t)tile * stride[l]);
+    }
+    __device__ __forceinline__ void store(bf16* lds) const {
+#pragma unroll
+        for (int l = 0; l < MAXL; ++l) if (on[l]) *reinterpret_cast<bf16x8*>(lds + lds_piece[l] * 8) = reg[l];
+    }
+};
 
 // per-(batch,head) dropout stream on the probabilities: 32-bit index q*Tp + key, one hash word per key pair
 __device__ __forceinline__ void drop_probs_qlane(f32x16& v, const DropCfg& dc, uint32_t base, int hh) {
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {       // registers (i, i+1) hold adjacent keys
-        const uint32_t w = drop_word(dc.s0, dc.s1, (base + (uint32_t)acc32_row(i, hh)) >> 1);
+        const uint32_t w = drop_word_idx32(dc, base + (uint32_t)acc32_row(i, hh));
         v[i] = drop_lo(dc, w, v[i]); v[i + 1] = drop_hi(dc, w, v[i + 1]);
     }
 }
@@ -38,60 +69,67 @@ __device__ __forceinline__ void drop_probs_qlane(f32x16& v, const DropCfg& dc, u
 #define MMT_RESCALE_THR 8.0f
 
 template <int DKP, bool DROP>
-__global__ __launch_bounds__(MMT_THREADS) void attn_fwd_kernel(
+__global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
         const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vt,
         bf16* __restrict__ ctx, bf16* __restrict__ ctxT, float* __restrict__ lse,
         int h, int T, int nt, int ldc, int MP, DropCfg drop) {
     constexpr int KS = DKP / 16;
     constexpr bool ONES = (DKP == 16) && !DROP;        // row sums through the MFMA
+    constexpr int PK = DKP * 4, PV = 128;              // 16-byte pieces of one K (R layout) / V (T layout) tile
+    __shared__ __attribute__((aligned(16))) bf16 stage[2][(PK + PV) * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int qt = blockIdx.x * 4 + wave;
-    if (qt >= nt) return;
+    const bool live = qt < nt;                          // idle waves still stage and synchronise
+    const int qtc = live ? qt : nt - 1;
     const int bh = blockIdx.y, b = bh / h, head = bh - b * h;
     const int Tp = nt * 32;
     const bf16* Qb = Qr + (size_t)bh * fragR_elems(Tp, DKP);
     const bf16* Kb = Kr + (size_t)bh * fragR_elems(Tp, DKP);
     const bf16* Vb = Vt + (size_t)bh * fragT_elems(Tp);
-    DropCfg dc = drop;
-    dc.s0 += (uint32_t)bh * 0x7F4A7C15u;
+    const DropCfg dc = DROP ? drop_substream(drop, (uint32_t)bh) : drop;       // per-(batch,head) stream
 
-    bf16x8 qf[KS], kf[KS], vf[2], kn[KS], vn[2];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        qf[s] = *reinterpret_cast<const bf16x8*>(Qb + ((size_t)(qt * (DKP / 8) + 2 * s + hh) * 32 + r) * 8);
-        kf[s] = *reinterpret_cast<const bf16x8*>(Kb + ((size_t)(2 * s + hh) * 32 + r) * 8);
+    TileStager<2> stg;
+    {
+        const bf16* base[2] = {Kb, Vb};
+        const int pieces[2] = {PK, PV}, strides[2] = {32 * DKP, 1024};
+        stg.init(base, pieces, strides, threadIdx.x);
     }
+    stg.load(0);
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        qf[s] = *reinterpret_cast<const bf16x8*>(Qb + ((size_t)(qtc * (DKP / 8) + 2 * s + hh) * 32 + r) * 8);
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) vf[s2] = *reinterpret_cast<const bf16x8*>(Vb + ((size_t)(s2 * 2 + hh) * 32 + r) * 8);
+    stg.store(stage[0]);
+    __syncthreads();
 
     f32x16 o;
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = 0.f;
     float mrun = 0.f, lrun = 0.f;
 
-    for (int kt = 0; kt < nt; ++kt) {
-        if (kt + 1 < nt) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-                kn[s] = *reinterpret_cast<const bf16x8*>(Kb + ((size_t)((kt + 1) * (DKP / 8) + 2 * s + hh) * 32 + r) * 8);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-                vn[s2] = *reinterpret_cast<const bf16x8*>(Vb + ((size_t)(((kt + 1) * 2 + s2) * 2 + hh) * 32 + r) * 8);
-        }
+    // The tile body is instantiated twice: TAIL = false for the hot loop (no conditional code between an MFMA and the
+    // consumers of its result: hipcc's hazard recognizer counts a skippable block's instructions as MFMA->VALU wait
+    // states, which is wrong on the taken path — seen as 27 % wrong dQ in attn_bwd_dq_kernel<32>), TAIL = true for the
+    // last key tile, whose index masking is then straight-line code.
+    auto body = [&](auto tail_tag, int kt) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        if (!TAIL) stg.load(kt + 1);                    // next tile in flight behind this tile's arithmetic
+        const bf16* sk = stage[kt & 1];
+        const bf16* sv = sk + PK * 8;
         f32x16 s;
         const float init = (kt == 0) ? 0.f : -mrun;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = init;
 #pragma unroll
-        for (int ss = 0; ss < KS; ++ss) s = mfma32(kf[ss], qf[ss], s);
-        if (kt == nt - 1 && (T & 31)) {                // keys >= T do not exist
+        for (int ss = 0; ss < KS; ++ss)
+            s = mfma32(*reinterpret_cast<const bf16x8*>(sk + ((2 * ss + hh) * 32 + r) * 8), qf[ss], s);
+        if (TAIL) {                                     // keys >= T do not exist
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (kt * 32 + acc32_row(i, hh) >= T) s[i] = -INFINITY;
+            for (int i = 0; i < 16; ++i) s[i] = (kt * 32 + acc32_row(i, hh) < T) ? s[i] : -INFINITY;
         }
         float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
@@ -111,19 +149,19 @@ __global__ __launch_bounds__(MMT_THREADS) void attn_fwd_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s[i] = fast_exp2(s[i]); if (!ONES) psum += s[i]; }
         if (!ONES) lrun += psum;
-        if (DROP) drop_probs_qlane(s, dc, (uint32_t)(qt * 32 + r) * (uint32_t)Tp + (uint32_t)(kt * 32), hh);
+        if (DROP) drop_probs_qlane(s, dc, (uint32_t)(qtc * 32 + r) * (uint32_t)Tp + (uint32_t)(kt * 32), hh);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 va = vf[s2];
+            bf16x8 va = *reinterpret_cast<const bf16x8*>(sv + ((s2 * 2 + hh) * 32 + r) * 8);
             if (ONES && r == DKP) va = ones;           // V^T rows >= DKP are zero in memory; row DKP becomes the ones row
             o = mfma32(va, pack8(s, s2), o);
         }
-        if (kt + 1 < nt) {
-#pragma unroll
-            for (int ss = 0; ss < KS; ++ss) kf[ss] = kn[ss];
-            vf[0] = vn[0]; vf[1] = vn[1];
-        }
-    }
+        if (!TAIL) stg.store(stage[(kt + 1) & 1]);
+        __syncthreads();        // stage[(kt+1)&1] was last read at tile kt-1, i.e. before the previous barrier
+    };
+    for (int kt = 0; kt < nt - 1; ++kt) body(std::false_type{}, kt);
+    body(std::true_type{}, nt - 1);
+    if (!live) return;
     float ltot;
     if (ONES) ltot = __shfl(o[8], r);                  // O^T row 16 = (register 8, lower half): the row sums
     else ltot = lrun + __shfl_xor(lrun, 32);
@@ -131,7 +169,7 @@ __global__ __launch_bounds__(MMT_THREADS) void attn_fwd_kernel(
     const int t = qt * 32 + r;
     if (t < T) {
         const size_t m = (size_t)b * T + t;
-        if (hh == 0) lse[(size_t)bh * Tp + t] = mrun + fast_log2(ltot);
+        if (hh == 0) lse[(size_t)bh * Tp + t] = -(mrun + fast_log2(ltot));   // stored NEGATED: it is the accumulator init of the backward
         // O^T rows (head features) live in registers: e = acc32_row(i, hh); groups of 4 are contiguous
 #pragma unroll
         for (int g = 0; g < DKP / 8; ++g) {
@@ -149,11 +187,11 @@ __global__ __launch_bounds__(MMT_THREADS) void attn_fwd_kernel(
 // ------------------------------------------------------------------------------------------------
 // Backward, part A: dK, dV.  Wave w owns key tile kt = 4*blockIdx.x + w (the key on the lane column) and
 // sweeps all query tiles, keeping dK^T, dV^T in accumulators.  Per query tile:
-//     S'  = Q' K^T - L      (L preloaded as the accumulator rows: P = 2^S' needs no subtraction)
-//     dPc = dO V^T - delta  (same trick with delta = rowsum(dO . O))
+//     S'  = Q' K^T - L      (-L, stored negated, is the accumulator init: P = 2^S' needs no subtraction)
+//     dPc = dO V^T - delta  (same trick with -delta = -rowsum(dO . O))
 //     dS  = P * dPc ;  dV^T += dO^T P ;  dK^T += Q'^T dS     (P, dS accumulators ARE the B operands)
 template <int DKP, bool DROP>
-__global__ __launch_bounds__(MMT_THREADS) void attn_bwd_dkv_kernel(
+__global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dkv_kernel(
         const bf16* __restrict__ Qr, const bf16* __restrict__ Qt, const bf16* __restrict__ Kr, const bf16* __restrict__ Vr,
         const bf16* __restrict__ dOr, const bf16* __restrict__ dOt,
         const float* __restrict__ lse, const float* __restrict__ delta,
@@ -161,91 +199,113 @@ __global__ __launch_bounds__(MMT_THREADS) void attn_bwd_dkv_kernel(
         bf16* __restrict__ dkvT, int MP,        // T layout  [3*HD rows][MP]
         int h, int T, int nt, DropCfg drop) {
     constexpr int KS = DKP / 16;
+    constexpr int PR = DKP * 4, PT = 128, PC = 8;       // pieces: R-layout tile, T-layout tile, 32 fp32 row constants
+    constexpr int TOTAL = 2 * PR + 2 * PT + 2 * PC;
+    __shared__ __attribute__((aligned(16))) bf16 stage[2][TOTAL * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int kt = blockIdx.x * 4 + wave;
-    if (kt >= nt) return;
+    const bool live = kt < nt;
+    const int ktc = live ? kt : nt - 1;
     const int bh = blockIdx.y, b = bh / h, head = bh - b * h;
     const int Tp = nt * 32, HD = h * DKP;
     const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
-    const bf16 *Qrb = Qr + offR, *Krb = Kr + offR, *Vrb = Vr + offR, *dOrb = dOr + offR;
-    const bf16 *Qtb = Qt + offT, *dOtb = dOt + offT;
-    const float* lseb = lse + (size_t)bh * Tp;
-    const float* delb = delta + (size_t)bh * Tp;
-    DropCfg dc = drop;
-    dc.s0 += (uint32_t)bh * 0x7F4A7C15u;
+    const bf16 *Krb = Kr + offR, *Vrb = Vr + offR;
+    const DropCfg dc = DROP ? drop_substream(drop, (uint32_t)bh) : drop;       // per-(batch,head) stream
 
+    TileStager<6> stg;
+    {
+        const bf16* base[6] = {Qr + offR, dOr + offR, Qt + offT, dOt + offT,
+                               reinterpret_cast<const bf16*>(lse + (size_t)bh * Tp), reinterpret_cast<const bf16*>(delta + (size_t)bh * Tp)};
+        const int pieces[6] = {PR, PR, PT, PT, PC, PC}, strides[6] = {32 * DKP, 32 * DKP, 1024, 1024, 64, 64};
+        stg.init(base, pieces, strides, threadIdx.x);
+    }
+    stg.load(0);
     bf16x8 kfr[KS], vfr[KS];
 #pragma unroll
     for (int ss = 0; ss < KS; ++ss) {
-        const size_t off = ((size_t)(kt * (DKP / 8) + 2 * ss + hh) * 32 + r) * 8;
+        const size_t off = ((size_t)(ktc * (DKP / 8) + 2 * ss + hh) * 32 + r) * 8;
         kfr[ss] = *reinterpret_cast<const bf16x8*>(Krb + off);
         vfr[ss] = *reinterpret_cast<const bf16x8*>(Vrb + off);
     }
     f32x16 dKacc, dVacc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) { dKacc[j] = 0.f; dVacc[j] = 0.f; }
-    const bool key_tail = (kt == nt - 1) && (T & 31);
-    const bool key_ok = (kt * 32 + r) < T;
-    const uint32_t kcol = (uint32_t)(kt * 32 + r);
+    const bool key_tail = (ktc == nt - 1) && (T & 31);
+    const bool key_ok = (ktc * 32 + r) < T;
+    const uint32_t kcol = (uint32_t)(ktc * 32 + r);
+    stg.store(stage[0]);
+    __syncthreads();
 
-    for (int qt = 0; qt < nt; ++qt) {
-        bf16x8 qa[KS], da[KS], qT[2], dT[2];
-#pragma unroll
-        for (int ss = 0; ss < KS; ++ss) {
-            const size_t off = ((size_t)(qt * (DKP / 8) + 2 * ss + hh) * 32 + r) * 8;
-            qa[ss] = *reinterpret_cast<const bf16x8*>(Qrb + off);
-            da[ss] = *reinterpret_cast<const bf16x8*>(dOrb + off);
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const size_t off = ((size_t)((qt * 2 + s2) * 2 + hh) * 32 + r) * 8;
-            qT[s2] = *reinterpret_cast<const bf16x8*>(Qtb + off);
-            dT[s2] = *reinterpret_cast<const bf16x8*>(dOtb + off);
-        }
+    // Tile body without conditional code (see attn_fwd_kernel): the key-tail mask is a per-lane multiplier that is
+    // simply 1 everywhere except in the wave that owns the last key tile, and the query tail is the peeled last tile.
+    const float kmul = (key_tail && !key_ok) ? 0.f : 1.f;
+    auto body = [&](auto tail_tag, int qt) {
+        constexpr bool QTAIL = decltype(tail_tag)::value;
+        const bool more = qt + 1 < nt;                  // scalar, loop-invariant except at the very last tile
+        if (more) stg.load(qt + 1);
+        const bf16* sq = stage[qt & 1];
+        const bf16* sdo = sq + PR * 8;
+        const bf16* sqt = sq + 2 * PR * 8;
+        const bf16* sdt = sqt + PT * 8;
+        const float* sl = reinterpret_cast<const float*>(sdt + PT * 8);
+        const float* sd = sl + 32;
         f32x16 s, dp;                   // row constants (4 consecutive queries per register group) as the accumulators
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lseb + qt * 32 + 8 * g + 4 * hh);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(delb + qt * 32 + 8 * g + 4 * hh);
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl + 8 * g + 4 * hh);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + 8 * g + 4 * hh);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { s[4 * g + i] = -l4[i]; dp[4 * g + i] = -d4[i]; }
+            for (int i = 0; i < 4; ++i) { s[4 * g + i] = l4[i]; dp[4 * g + i] = d4[i]; }      // both stored negated
         }
         f32x16 negD;
         if (DROP) negD = dp;
 #pragma unroll
-        for (int ss = 0; ss < KS; ++ss) { s = mfma32(qa[ss], kfr[ss], s); dp = mfma32(da[ss], vfr[ss], dp); }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) s[j] = fast_exp2(s[j]);
-        if (key_tail) {                                 // keys >= T do not exist
-#pragma unroll
-            for (int j = 0; j < 16; ++j) s[j] = key_ok ? s[j] : 0.f;
+        for (int ss = 0; ss < KS; ++ss) {
+            const int o8 = ((2 * ss + hh) * 32 + r) * 8;
+            s = mfma32(*reinterpret_cast<const bf16x8*>(sq + o8), kfr[ss], s);
+            dp = mfma32(*reinterpret_cast<const bf16x8*>(sdo + o8), vfr[ss], dp);
         }
-        if (qt == nt - 1 && (T & 31)) {                 // neither do queries >= T
 #pragma unroll
-            for (int j = 0; j < 16; ++j) if (qt * 32 + acc32_row(j, hh) >= T) s[j] = 0.f;
+        for (int j = 0; j < 16; ++j) {
+            float pv = fast_exp2(s[j]);
+            if (QTAIL) pv = (qt * 32 + acc32_row(j, hh) < T) ? pv : 0.f;      // queries >= T do not exist
+            s[j] = pv;
         }
         if (DROP) {
             // dropped probabilities Pd = P*m/(1-p):  dV^T += dO^T Pd ;  dS = P * ((dO V^T)*m/(1-p) - delta); delta unchanged
-            const uint32_t q0 = (uint32_t)(qt * 32) * (uint32_t)Tp + kcol;
+            // pair index (q*Tp + key) >> 1 = q*(Tp/2) + key/2 (Tp is even); this lane's half of the word is fixed by its key parity
+            const uint32_t hTp = (uint32_t)Tp >> 1;
+            const uint32_t p0 = (uint32_t)(qt * 32 + 4 * hh) * hTp + (kcol >> 1);
+            const uint32_t sh = (kcol & 1) * 16;
+            const float keep_scale = dc.scale * kmul;   // keys >= T: multiplier 0
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const uint32_t idx = q0 + (uint32_t)acc32_row(j, hh) * (uint32_t)Tp;
-                const uint32_t w = drop_word(dc.s0, dc.s1, idx >> 1);
-                const float ms = (((idx & 1) ? (w >> 16) : (w & 0xFFFFu)) >= dc.thr16) ? dc.scale : 0.f;
-                dp[j] = s[j] * ((dp[j] - negD[j]) * ms + negD[j]);
+                const uint32_t w = drop_word(dc.s0, dc.s1, p0 + (uint32_t)((j & 3) + 8 * (j >> 2)) * hTp);
+                const float ms = (((w >> sh) & 0xFFFFu) >= dc.thr16) ? keep_scale : 0.f;
+                dp[j] = (s[j] * kmul) * ((dp[j] - negD[j]) * ms + negD[j]);
                 s[j] *= ms;
             }
         } else {
+            if (key_tail) {                             // wave-uniform, loop-invariant: only the last key tile's wave pays
+#pragma unroll
+                for (int j = 0; j < 16; ++j) s[j] *= kmul;
+            }
 #pragma unroll
             for (int j = 0; j < 16; ++j) dp[j] *= s[j];
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            dVacc = mfma32(dT[s2], pack8(s, s2), dVacc);
-            dKacc = mfma32(qT[s2], pack8(dp, s2), dKacc);
+            const int o8 = ((s2 * 2 + hh) * 32 + r) * 8;
+            dVacc = mfma32(*reinterpret_cast<const bf16x8*>(sdt + o8), pack8(s, s2), dVacc);
+            dKacc = mfma32(*reinterpret_cast<const bf16x8*>(sqt + o8), pack8(dp, s2), dKacc);
         }
-    }
+        if (more) stg.store(stage[(qt + 1) & 1]);
+        __syncthreads();
+    };
+    for (int qt = 0; qt < nt - 1; ++qt) body(std::false_type{}, qt);
+    if (T & 31) body(std::true_type{}, nt - 1); else body(std::false_type{}, nt - 1);
+    if (!live) return;
     // dK = ln2 * acc (scores are in the log2 domain), dV = acc; rows e = acc32_row, column key = r
     const float LN2 = 0.6931471805599453f;
     const int t = kt * 32 + r;
@@ -274,70 +334,76 @@ __global__ __launch_bounds__(MMT_THREADS) void attn_bwd_dkv_kernel(
 // (keys in registers) is the B operand of dQ^T += K^T dS^T.  The epilogue applies 1/sqrt(d_k) and the
 // query-row mask (blanked rows pass no gradient to Q) and writes columns [0,HD) of dQKV in both layouts.
 template <int DKP, bool DROP>
-__global__ __launch_bounds__(MMT_THREADS) void attn_bwd_dq_kernel(
+__global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
         const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Kt, const bf16* __restrict__ Vr,
         const bf16* __restrict__ dOr, const float* __restrict__ lse, const float* __restrict__ delta,
         const float* __restrict__ rowmask, float scale,
         bf16* __restrict__ dqkv, int lddqkv, bf16* __restrict__ dqkvT, int MP,
         int h, int T, int nt, DropCfg drop) {
     constexpr int KS = DKP / 16;
+    constexpr int PR = DKP * 4, PT = 128;
+    __shared__ __attribute__((aligned(16))) bf16 stage[2][(2 * PR + PT) * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int qt = blockIdx.x * 4 + wave;
-    if (qt >= nt) return;
+    const bool live = qt < nt;
+    const int qtc = live ? qt : nt - 1;
     const int bh = blockIdx.y, b = bh / h, head = bh - b * h;
     const int Tp = nt * 32;
     const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
-    const bf16 *Qrb = Qr + offR, *Krb = Kr + offR, *Vrb = Vr + offR, *dOrb = dOr + offR, *Ktb = Kt + offT;
-    DropCfg dc = drop;
-    dc.s0 += (uint32_t)bh * 0x7F4A7C15u;
+    const bf16 *Qrb = Qr + offR, *dOrb = dOr + offR;
+    const DropCfg dc = DROP ? drop_substream(drop, (uint32_t)bh) : drop;       // per-(batch,head) stream
 
-    bf16x8 qf[KS], dof[KS], kf[KS], vf[KS], ktf[2], kn[KS], vn[KS], ktn[2];
+    TileStager<3> stg;
+    {
+        const bf16* base[3] = {Kr + offR, Vr + offR, Kt + offT};
+        const int pieces[3] = {PR, PR, PT}, strides[3] = {32 * DKP, 32 * DKP, 1024};
+        stg.init(base, pieces, strides, threadIdx.x);
+    }
+    stg.load(0);
+    bf16x8 qf[KS], dof[KS];
 #pragma unroll
     for (int ss = 0; ss < KS; ++ss) {
-        const size_t off = ((size_t)(qt * (DKP / 8) + 2 * ss + hh) * 32 + r) * 8;
+        const size_t off = ((size_t)(qtc * (DKP / 8) + 2 * ss + hh) * 32 + r) * 8;
         qf[ss] = *reinterpret_cast<const bf16x8*>(Qrb + off);
         dof[ss] = *reinterpret_cast<const bf16x8*>(dOrb + off);
-        const size_t off0 = ((size_t)(2 * ss + hh) * 32 + r) * 8;
-        kf[ss] = *reinterpret_cast<const bf16x8*>(Krb + off0);
-        vf[ss] = *reinterpret_cast<const bf16x8*>(Vrb + off0);
     }
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) ktf[s2] = *reinterpret_cast<const bf16x8*>(Ktb + ((size_t)(s2 * 2 + hh) * 32 + r) * 8);
-    const float negL = -lse[(size_t)bh * Tp + qt * 32 + r];
-    const float negD = -delta[(size_t)bh * Tp + qt * 32 + r];
+    const float negL = lse[(size_t)bh * Tp + qtc * 32 + r];          // both stored negated by their producers
+    const float negD = delta[(size_t)bh * Tp + qtc * 32 + r];
     f32x16 dq;
 #pragma unroll
     for (int j = 0; j < 16; ++j) dq[j] = 0.f;
+    stg.store(stage[0]);
+    __syncthreads();
 
-    for (int kt = 0; kt < nt; ++kt) {
-        if (kt + 1 < nt) {
-#pragma unroll
-            for (int ss = 0; ss < KS; ++ss) {
-                const size_t off = ((size_t)((kt + 1) * (DKP / 8) + 2 * ss + hh) * 32 + r) * 8;
-                kn[ss] = *reinterpret_cast<const bf16x8*>(Krb + off);
-                vn[ss] = *reinterpret_cast<const bf16x8*>(Vrb + off);
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-                ktn[s2] = *reinterpret_cast<const bf16x8*>(Ktb + ((size_t)(((kt + 1) * 2 + s2) * 2 + hh) * 32 + r) * 8);
-        }
+    // Tile body without conditional code between MFMAs and their consumers (see attn_fwd_kernel); key tail peeled.
+    auto body = [&](auto tail_tag, int kt) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        const bool more = kt + 1 < nt;
+        if (more) stg.load(kt + 1);
+        const bf16* sk = stage[kt & 1];
+        const bf16* sv = sk + PR * 8;
+        const bf16* skt = sv + PR * 8;
         f32x16 s, dp;
 #pragma unroll
         for (int j = 0; j < 16; ++j) { s[j] = negL; dp[j] = negD; }
 #pragma unroll
-        for (int ss = 0; ss < KS; ++ss) { s = mfma32(kf[ss], qf[ss], s); dp = mfma32(vf[ss], dof[ss], dp); }
+        for (int ss = 0; ss < KS; ++ss) {
+            const int o8 = ((2 * ss + hh) * 32 + r) * 8;
+            s = mfma32(*reinterpret_cast<const bf16x8*>(sk + o8), qf[ss], s);
+            dp = mfma32(*reinterpret_cast<const bf16x8*>(sv + o8), dof[ss], dp);
+        }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) s[j] = fast_exp2(s[j]);
-        if (kt == nt - 1 && (T & 31)) {                 // keys >= T do not exist
-#pragma unroll
-            for (int j = 0; j < 16; ++j) if (kt * 32 + acc32_row(j, hh) >= T) s[j] = 0.f;
+        for (int j = 0; j < 16; ++j) {
+            float pv = fast_exp2(s[j]);
+            if (TAIL) pv = (kt * 32 + acc32_row(j, hh) < T) ? pv : 0.f;       // keys >= T do not exist
+            s[j] = pv;
         }
         if (DROP) {
-            const uint32_t base = (uint32_t)(qt * 32 + r) * (uint32_t)Tp + (uint32_t)(kt * 32);
+            const uint32_t base = (uint32_t)(qtc * 32 + r) * (uint32_t)Tp + (uint32_t)(kt * 32);
 #pragma unroll
             for (int j = 0; j < 16; j += 2) {
-                const uint32_t w = drop_word(dc.s0, dc.s1, (base + (uint32_t)acc32_row(j, hh)) >> 1);
+                const uint32_t w = drop_word_idx32(dc, base + (uint32_t)acc32_row(j, hh));
                 const float m0 = ((w & 0xFFFFu) >= dc.thr16) ? dc.scale : 0.f, m1 = ((w >> 16) >= dc.thr16) ? dc.scale : 0.f;
                 dp[j] = s[j] * ((dp[j] - negD) * m0 + negD);
                 dp[j + 1] = s[j + 1] * ((dp[j + 1] - negD) * m1 + negD);
@@ -347,13 +413,14 @@ __global__ __launch_bounds__(MMT_THREADS) void attn_bwd_dq_kernel(
             for (int j = 0; j < 16; ++j) dp[j] *= s[j];
         }
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) dq = mfma32(ktf[s2], pack8(dp, s2), dq);
-        if (kt + 1 < nt) {
-#pragma unroll
-            for (int ss = 0; ss < KS; ++ss) { kf[ss] = kn[ss]; vf[ss] = vn[ss]; }
-            ktf[0] = ktn[0]; ktf[1] = ktn[1];
-        }
-    }
+        for (int s2 = 0; s2 < 2; ++s2)
+            dq = mfma32(*reinterpret_cast<const bf16x8*>(skt + ((s2 * 2 + hh) * 32 + r) * 8), pack8(dp, s2), dq);
+        if (more) stg.store(stage[(kt + 1) & 1]);
+        __syncthreads();
+    };
+    for (int kt = 0; kt < nt - 1; ++kt) body(std::false_type{}, kt);
+    if (T & 31) body(std::true_type{}, nt - 1); else body(std::false_type{}, nt - 1);
+    if (!live) return;
     const int t = qt * 32 + r;
     if (t < T) {
         const size_t m = (size_t)b * T + t;

@@ -79,32 +79,61 @@ __host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m -
 // element compares its 16-bit half with thr16 = round(p * 65536): P(drop) = thr16/65536 (exact to 1.5e-5),
 // kept values are scaled by 65536/(65536 - thr16).  A mask is a pure function of (seed, stream, index), so the
 // backward pass regenerates it instead of storing it.
+//   * stream keys (s0, s1) are mixed on the host (splitmix64 of seed and stream id);
+//   * the per-word hash uses only FULL-RATE integer ops (v_mad_u32_u24 + shifts/xors: 9 instructions;
+//     v_mul_lo_u32 is quarter rate on CDNA) — the attention kernels are VALU-issue bound and evaluate it per score.
+//     It avalanches a 24-bit pair index; callers fold higher index bits into s0.
 struct DropCfg { uint32_t thr16; float scale; uint32_t s0, s1; };
 
 __device__ __forceinline__ uint32_t drop_word(uint32_t s0, uint32_t s1, uint32_t pair) {
-    uint32_t x = pair * 0x9E3779B1u + s0;
+    uint32_t x = __umul24(pair, 0xD2B54Bu) + s0;
+    x ^= x >> 15;
+    x ^= s1;
+    x = __umul24(x, 0x9E3779u) + (x >> 24);
+    x ^= x >> 14;
+    return x;
+}
+// strong (3 full multiplies) mixer for once-per-wave key derivation, e.g. the per-(batch,head) attention streams
+__device__ __forceinline__ uint32_t mix32(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t x = c * 0x9E3779B1u + a;
     x ^= x >> 15; x *= 0x85EBCA6Bu;
-    x ^= x >> 13; x += s1; x *= 0xC2B2AE35u;
+    x ^= x >> 13; x += b; x *= 0xC2B2AE35u;
     x ^= x >> 16;
     return x;
 }
+__device__ __forceinline__ DropCfg drop_substream(const DropCfg& c, uint32_t id) {
+    DropCfg d = c;
+    d.s0 = mix32(c.s0, c.s1, id);
+    d.s1 = mix32(c.s1, c.s0, id ^ 0x5bd1e995u);
+    return d;
+}
 __device__ __forceinline__ bool drop_keep(const DropCfg& c, uint64_t idx) {
-    const uint32_t w = drop_word(c.s0 + (uint32_t)(idx >> 33) * 0x7F4A7C15u, c.s1, (uint32_t)(idx >> 1));
+    const uint32_t w = drop_word(c.s0 + __umul24((uint32_t)(idx >> 25), 0x4A7C15u), c.s1, (uint32_t)(idx >> 1));
     return ((idx & 1) ? (w >> 16) : (w & 0xFFFFu)) >= c.thr16;
 }
 // pair form for an EVEN index: one hash word decides idx (low half) and idx+1 (high half)
 __device__ __forceinline__ uint32_t drop_pair(const DropCfg& c, uint64_t even_idx) {
-    return drop_word(c.s0 + (uint32_t)(even_idx >> 33) * 0x7F4A7C15u, c.s1, (uint32_t)(even_idx >> 1));
+    return drop_word(c.s0 + __umul24((uint32_t)(even_idx >> 25), 0x4A7C15u), c.s1, (uint32_t)(even_idx >> 1));
 }
 __device__ __forceinline__ float drop_lo(const DropCfg& c, uint32_t w, float v) { return (w & 0xFFFFu) >= c.thr16 ? v * c.scale : 0.f; }
 __device__ __forceinline__ float drop_hi(const DropCfg& c, uint32_t w, float v) { return (w >> 16) >= c.thr16 ? v * c.scale : 0.f; }
-// stream = which dropout site of which layer; keeps the sites statistically independent
+// 32-bit index form used by the attention kernels (index = q*Tp + key inside one (batch,head) stream)
+// (host code rejects dropout for Tp > 4096, so the pair index q*Tp/2 + key/2 always fits the 24-bit multiply)
+__device__ __forceinline__ uint32_t drop_word_idx32(const DropCfg& c, uint32_t idx) { return drop_word(c.s0, c.s1, idx >> 1); }
+// stream = which dropout site of which layer
+__host__ __device__ inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
 __host__ __device__ inline DropCfg make_drop(float p, uint64_t seed, uint32_t stream) {
     DropCfg c;
     double t = (double)p * 65536.0 + 0.5;
     c.thr16 = p <= 0.f ? 0u : (t >= 65535.0 ? 65535u : (uint32_t)t);
     c.scale = 65536.0f / (65536.0f - (float)c.thr16);
-    c.s0 = (uint32_t)seed ^ (stream * 0x632BE5ABu);
-    c.s1 = (uint32_t)(seed >> 32) + stream * 0x9E3779B9u;
+    const uint64_t k = splitmix64(splitmix64(seed) + 0x100000001B3ull * (uint64_t)stream);
+    c.s0 = (uint32_t)k;
+    c.s1 = (uint32_t)(k >> 32);
     return c;
 }

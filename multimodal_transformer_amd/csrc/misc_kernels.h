@@ -225,7 +225,7 @@ struct WgradJob {
 #define MMT_MAX_WGRAD_JOBS 64
 struct WgradJobs { WgradJob j[MMT_MAX_WGRAD_JOBS]; int njobs; int MP; int M16; int mchunk; };
 
-__global__ __launch_bounds__(MMT_THREADS) void wgrad_kernel(const WgradJobs jobs) {
+__global__ __launch_bounds__(MMT_THREADS, 2) void wgrad_kernel(const WgradJobs jobs) {
     // Operand tiles [64 features][64 windows] are fetched with full 128-byte lines (8 lanes x 16 B per feature row),
     // the next chunk already in registers while the current one is multiplied out of LDS; rows are padded to 144 B so
     // the 32-row x 16-byte fragment reads (ds_read_b128) are bank-conflict free.

@@ -42,7 +42,7 @@ struct RowGemmParams {
     bf16* fragR[3]; bf16* fragT[3];
     int T, Tp, h, DKP, nwhich;             // N covers nwhich * h * DKP columns
     const float* rowmask; float qscale; int scale_first;   // first matrix: *qscale and zero where rowmask==0
-    const bf16* ctx; int ldctx; float* delta;              // delta[bh][Tp] = sum_e C*ctx (dO epilogue)
+    const bf16* ctx; int ldctx; float* delta;              // delta[bh][Tp] = -sum_e C*ctx (dO epilogue; stored negated)
     // ---- LNBWD ----
     const float* x; int ldx; const float* st; const float* dres; int lddres;
     float* colpart;                        // [gridDim.x][2][NP]: per-workgroup column sums (d ln_b, d ln_a)
@@ -63,7 +63,7 @@ inline size_t rowgemm_lds_bytes(int EPI, bool lnpro, int KP, int NP) {
 }
 
 template <int EPI, bool LNPRO>
-__global__ __launch_bounds__(MMT_THREADS) void rowgemm_kernel(const RowGemmParams p) {
+__global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int KP = p.KP, NP = p.NP, K = p.K, M = p.M;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(MMT_THREADS) void rowgemm_kernel(const RowGemmParam
                 if (p.delta) {
                     part += __shfl_xor(part, 1); part += __shfl_xor(part, 2);
                     if (nred == 8) part += __shfl_xor(part, 4);
-                    if (ok && e == 0) p.delta[(size_t)bh * p.Tp + t] = part;
+                    if (ok && e == 0) p.delta[(size_t)bh * p.Tp + t] = -part;      // stored negated (accumulator init of the backward)
                 }
             }
         }
