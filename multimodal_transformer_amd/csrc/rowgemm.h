@@ -73,6 +73,22 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
     float* Fs = reinterpret_cast<float*>(smem + (size_t)32 * lda_s * 2);
     float* Gs = Fs + (size_t)32 * ldf;                          // LNBWD only
     const int m0 = blockIdx.x * 32;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    // W fragments of the first chunk's first two k-blocks go in flight NOW: their L2 latency overlaps the A-tile staging
+    bf16x8 b00, b01, b10, b11, n00, n01, n10, n11;
+    {
+        const int nb = wave * 32;
+        const bf16* wrow0 = p.W + (size_t)((nb < NP ? nb : 0) + l15) * KP + 8 * lq;
+        const bf16* wrow1 = wrow0 + (size_t)16 * KP;
+        b00 = *reinterpret_cast<const bf16x8*>(wrow0); b01 = *reinterpret_cast<const bf16x8*>(wrow1);
+        b10 = *reinterpret_cast<const bf16x8*>(wrow0 + 32); b11 = *reinterpret_cast<const bf16x8*>(wrow1 + 32);
+        n00 = b00; n01 = b01; n10 = b10; n11 = b11;
+        if (KP > 64) {
+            n00 = *reinterpret_cast<const bf16x8*>(wrow0 + 64); n01 = *reinterpret_cast<const bf16x8*>(wrow1 + 64);
+            n10 = *reinterpret_cast<const bf16x8*>(wrow0 + 96); n11 = *reinterpret_cast<const bf16x8*>(wrow1 + 96);
+        }
+    }
 
     // ------------------------------------------------------------------ 1. A tile -> LDS (bf16)
     if (LNPRO) {
@@ -161,7 +177,6 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
     }
 
     // ------------------------------------------------------------------ 2. chunks of 128 columns
-    const int l15 = lane & 15, lq = lane >> 4;
     for (int n0 = 0; n0 < NP; n0 += 128) {
         const int nb = n0 + wave * 32;
         if (nb < NP) {
@@ -174,13 +189,12 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
             const bf16* wrow1 = wrow0 + (size_t)16 * KP;
             const bf16* arow0 = As + l15 * lda_s + 8 * lq;
             const bf16* arow1 = arow0 + 16 * lda_s;
-            bf16x8 b00 = *reinterpret_cast<const bf16x8*>(wrow0);
-            bf16x8 b01 = *reinterpret_cast<const bf16x8*>(wrow1);
-            bf16x8 b10 = *reinterpret_cast<const bf16x8*>(wrow0 + 32);
-            bf16x8 b11 = *reinterpret_cast<const bf16x8*>(wrow1 + 32);
+            if (n0 > 0) {                    // (chunk 0's first fragments were issued before the A-tile staging)
+                b00 = *reinterpret_cast<const bf16x8*>(wrow0); b01 = *reinterpret_cast<const bf16x8*>(wrow1);
+                b10 = *reinterpret_cast<const bf16x8*>(wrow0 + 32); b11 = *reinterpret_cast<const bf16x8*>(wrow1 + 32);
+            }
             for (int kb = 0; kb < KP; kb += 64) {
-                bf16x8 n00 = b00, n01 = b01, n10 = b10, n11 = b11;
-                if (kb + 64 < KP) {          // next k-block's W fragments in flight behind this block's MFMAs
+                if (kb + 64 < KP && (kb > 0 || n0 > 0)) {   // next k-block's W fragments in flight behind this block's MFMAs
                     n00 = *reinterpret_cast<const bf16x8*>(wrow0 + kb + 64);
                     n01 = *reinterpret_cast<const bf16x8*>(wrow1 + kb + 64);
                     n10 = *reinterpret_cast<const bf16x8*>(wrow0 + kb + 96);
@@ -214,58 +228,87 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
 
         // -------------------------------------------------------------- 3. row-wise epilogue (chunk)
         if (EPI == EPI_PLAIN) {
+            // thread -> column group cg (4 columns, the same for its 4 tasks) and rows (tid>>5) + 8*it.
+            // Phase 1 issues every global load of the 4 tasks, phase 2 computes, phase 3 stores: stores through the
+            // (non-restrict) output pointers would otherwise fence the later tasks' loads and serialise 4 L2 round trips.
+            const int cg = tid & 31, n = n0 + cg * 4, rbase = tid >> 5;
+            const bool col_ok = n < NP;
+            f32x4 v[4], res[4];
+            bf16x4 mk[4];
+            float rs[4];
+            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+            if (col_ok && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            const bool res_vec = p.residual && (n + 4 <= p.N) && ((p.ldr & 3) == 0);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int task = tid + it * MMT_THREADS;
-                const int row = task >> 5, cg = task & 31, n = n0 + cg * 4, m = m0 + row;
-                if (n >= NP) continue;
-                f32x4 v = *reinterpret_cast<const f32x4*>(Fs + row * ldf + cg * 4);
+                const int row = rbase + 8 * it, m = m0 + row;
+                res[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                rs[it] = 1.f;
+                if (col_ok && m < M) {
+                    if (p.residual) {
+                        if (res_vec) res[it] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ldr + n);
+                        else for (int i = 0; i < 4; ++i) if (n + i < p.N) res[it][i] = p.residual[(size_t)m * p.ldr + n + i];
+                    }
+                    if (p.relu_mask) mk[it] = *reinterpret_cast<const bf16x4*>(p.relu_mask + (size_t)m * p.ldm + n);
+                    if (p.rowscale) rs[it] = p.rowscale[m];
+                }
+                v[it] = *reinterpret_cast<const f32x4*>(Fs + row * ldf + cg * 4);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = rbase + 8 * it, m = m0 + row;
+                if (!col_ok) continue;
+                f32x4 x = v[it];
                 if (m < M) {
-                    if (p.bias) { f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n); v += b; }
+                    x += bias4;
                     if (p.act == 1) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+                        for (int i = 0; i < 4; ++i) x[i] = fmaxf(x[i], 0.f);
                     } else if (p.act == 2) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = 2.0f * __builtin_amdgcn_rcpf(1.0f + fast_exp2(-2.8853900817779268f * v[i])) - 1.0f;
+                        for (int i = 0; i < 4; ++i) x[i] = 2.0f * __builtin_amdgcn_rcpf(1.0f + fast_exp2(-2.8853900817779268f * x[i])) - 1.0f;
                     } else if (p.act == 3) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_rcpf(1.0f + fast_exp2(-1.4426950408889634f * v[i]));
+                        for (int i = 0; i < 4; ++i) x[i] = __builtin_amdgcn_rcpf(1.0f + fast_exp2(-1.4426950408889634f * x[i]));
                     }
                     if (p.relu_mask) {
-                        bf16x4 mk = *reinterpret_cast<const bf16x4*>(p.relu_mask + (size_t)m * p.ldm + n);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = ((float)mk[i] > 0.f) ? v[i] * p.mask_scale : 0.f;
+                        for (int i = 0; i < 4; ++i) x[i] = ((float)mk[it][i] > 0.f) ? x[i] * p.mask_scale : 0.f;
                     }
                     if (p.drop.thr16) {
 #pragma unroll
                         for (int i = 0; i < 4; i += 2) {
                             const uint32_t w = drop_pair(p.drop, (uint64_t)m * NP + n + i);
-                            v[i] = drop_lo(p.drop, w, v[i]); v[i + 1] = drop_hi(p.drop, w, v[i + 1]);
+                            x[i] = drop_lo(p.drop, w, x[i]); x[i + 1] = drop_hi(p.drop, w, x[i + 1]);
                         }
                     }
-                    if (p.residual) {
+                    x += res[it];
+                    x *= rs[it];
+                } else {
+                    x = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                v[it] = x;
+            }
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) if (n + i < p.N) v[i] += p.residual[(size_t)m * p.ldr + n + i];
-                    }
-                    if (p.rowscale) { const float rs = p.rowscale[m]; v *= rs; }
+            for (int it = 0; it < 4; ++it) {
+                const int row = rbase + 8 * it, m = m0 + row;
+                if (!col_ok) continue;
+                if (m < M) {
                     if (p.out_f32) {
                         float* dst = p.out_f32 + (size_t)m * p.ldo + n;
-                        if (n + 4 <= p.N && (p.ldo & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
-                        else for (int i = 0; i < 4 && n + i < p.N; ++i) dst[i] = v[i];
+                        if (n + 4 <= p.N && (p.ldo & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v[it];
+                        else for (int i = 0; i < 4 && n + i < p.N; ++i) dst[i] = v[it][i];
                     }
                     if (p.out_bf16 && n < p.n_store16) {
                         bf16x4 o;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) o[i] = (bf16)v[i];
+                        for (int i = 0; i < 4; ++i) o[i] = (bf16)v[it][i];
                         bf16* dst = p.out_bf16 + (size_t)m * p.ldo16 + n;
                         if (n + 4 <= p.n_store16 && (p.ldo16 & 3) == 0) *reinterpret_cast<bf16x4*>(dst) = o;
                         else for (int i = 0; i < 4 && n + i < p.n_store16; ++i) dst[i] = o[i];
                     }
-                } else {
-                    v = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                if (p.out_T) *reinterpret_cast<f32x4*>(Fs + row * ldf + cg * 4) = v;   // final values for the T pass
+                if (p.out_T) *reinterpret_cast<f32x4*>(Fs + row * ldf + cg * 4) = v[it];   // final values for the T pass
             }
             if (p.out_T) {
                 __syncthreads();
@@ -286,42 +329,80 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
             const int HD = p.h * p.DKP;
             const size_t szR = fragR_elems(p.Tp, p.DKP), szT = fragT_elems(p.Tp);
             const int nred = p.DKP >> 2;                 // lanes per head (4 or 8), aligned groups
+            const bool fastT = (p.T & 3) == 0;           // 4 consecutive windows of a tile row group share (batch, s, hh): 8-byte T stores
+            const int cg = tid & 31, n = n0 + cg * 4, rbase = tid >> 5;
+            const bool col_ok = n < p.nwhich * HD;
+            int wi = 0, rem = 0, head = 0, e = 0;
+            if (col_ok) { wi = n / HD; rem = n - wi * HD; head = rem / p.DKP; e = rem - head * p.DKP; }
+            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+            if (col_ok && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            // phase 1: all global loads of the 4 tasks
+            float sc[4];
+            bf16x4 c4[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int task = tid + it * MMT_THREADS;
-                const int row = task >> 5, cg = task & 31, n = n0 + cg * 4, m = m0 + row;
-                const bool ok = (m < M) && (n < p.nwhich * HD);
+                const int m = m0 + rbase + 8 * it;
+                sc[it] = 1.f;
+                if (col_ok && m < M) {
+                    if (p.scale_first && wi == 0) sc[it] = (p.rowmask[m] == 0.0f) ? 0.f : p.qscale;   // mask == 0 -> blank query row
+                    if (p.delta) c4[it] = *reinterpret_cast<const bf16x4*>(p.ctx + (size_t)m * p.ldctx + rem);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = rbase + 8 * it, m = m0 + row;
+                const bool ok = col_ok && (m < M);
                 float part = 0.f;
-                int bh = 0, t = 0, e = 0;
+                int bh = 0, t = 0;
+                bf16x4 o = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
                 if (ok) {
-                    const int wi = n / HD, rem = n - wi * HD, head = rem / p.DKP;
-                    e = rem - head * p.DKP;
                     const int b = m / p.T;
                     t = m - b * p.T;
                     bh = b * p.h + head;
                     f32x4 v = *reinterpret_cast<const f32x4*>(Fs + row * ldf + cg * 4);
-                    if (p.bias) { f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + n); v += bb; }
-                    if (p.scale_first && wi == 0) {
-                        const float sc = (p.rowmask[m] == 0.0f) ? 0.f : p.qscale;   // mask == 0 -> blank query row
-                        v *= sc;
-                    }
-                    bf16x4 o;
+                    v += bias4;
+                    v *= sc[it];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[i] = (bf16)v[i];
                     *reinterpret_cast<bf16x4*>(p.fragR[wi] + bh * szR + fragR_index(t, e, p.DKP)) = o;
-                    bf16* dT = p.fragT[wi] + bh * szT;
+                    if (!fastT) {
+                        bf16* dT = p.fragT[wi] + bh * szT;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) dT[fragT_index(t, e + i)] = o[i];
-                    if (p.delta) {
-                        bf16x4 c4 = *reinterpret_cast<const bf16x4*>(p.ctx + (size_t)m * p.ldctx + rem);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) part += (float)o[i] * (float)c4[i];
+                        for (int i = 0; i < 4; ++i) dT[fragT_index(t, e + i)] = o[i];
                     }
+                    if (p.delta) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) part += (float)o[i] * (float)c4[it][i];
+                    }
+                }
+                if (fastT) {                             // bf16-rounded values back to the tile for the transposed pass
+                    f32x4 w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w[i] = (float)o[i];
+                    *reinterpret_cast<f32x4*>(Fs + row * ldf + cg * 4) = w;
                 }
                 if (p.delta) {
                     part += __shfl_xor(part, 1); part += __shfl_xor(part, 2);
                     if (nred == 8) part += __shfl_xor(part, 4);
                     if (ok && e == 0) p.delta[(size_t)bh * p.Tp + t] = -part;      // stored negated (accumulator init of the backward)
+                }
+            }
+            if (fastT) {
+                __syncthreads();
+                // task = (group of 4 consecutive rows, column): 4 column reads -> one 8-byte store into the T layout
+                const int c = tid & 127, nn = n0 + c;
+                if (nn < p.nwhich * HD) {
+                    const int wj = nn / HD, rj = nn - wj * HD, hj = rj / p.DKP, ej = rj - hj * p.DKP;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int rg = (tid >> 7) + 2 * it, mg = m0 + 4 * rg;
+                        if (mg >= M) continue;
+                        const int b = mg / p.T, t = mg - b * p.T;
+                        bf16x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = (bf16)Fs[(4 * rg + i) * ldf + c];
+                        *reinterpret_cast<bf16x4*>(p.fragT[wj] + (size_t)(b * p.h + hj) * szT + fragT_index(t, ej)) = o;
+                    }
                 }
             }
         }
@@ -337,6 +418,58 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
         float* gr = Gs + row * (NP + 4);
         float mean = 0.f, rstd = 0.f;
         if (m < M) { mean = p.st[2 * (size_t)m]; rstd = p.st[2 * (size_t)m + 1]; }
+        if (NP <= 256) {
+            // every global load (x, residual gradient, LayerNorm gain) of this thread's <= 8 column groups is issued first
+            constexpr int MAXIT = 8;
+            f32x4 xv[MAXIT], rv[MAXIT], av[MAXIT];
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int c = j * 4 + 32 * it;
+                xv[it] = f32x4{0.f, 0.f, 0.f, 0.f}; rv[it] = xv[it]; av[it] = xv[it];
+                if (m < M && c < d) {
+                    xv[it] = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + c);
+                    av[it] = *reinterpret_cast<const f32x4*>(p.ln_a + c);
+                    if (p.dres) rv[it] = *reinterpret_cast<const f32x4*>(p.dres + (size_t)m * p.lddres + c);
+                }
+            }
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int c = j * 4 + 32 * it;
+                if (c >= NP) continue;
+                f32x4 gx = {0.f, 0.f, 0.f, 0.f};
+                if (m < M && c < d) {
+                    const f32x4 dy = *reinterpret_cast<const f32x4*>(cr + c);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float xh = (xv[it][i] - mean) * rstd;
+                        const float g = dy[i] * av[it][i];
+                        s1 += g; s2 += g * xh;
+                        gx[i] = dy[i] * xh;
+                        xv[it][i] = xh;                      // keep xhat
+                    }
+                } else {
+                    *reinterpret_cast<f32x4*>(cr + c) = gx;  // zero the pad so the column sums ignore it
+                }
+                *reinterpret_cast<f32x4*>(gr + c) = gx;      // dy * xhat -> d ln_a; Fs keeps dy -> d ln_b
+            }
+            s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+            s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
+            if (m < M) {
+                const float sigma = 1.0f / rstd - p.eps;
+                const float k1 = s1 / (float)d, k2 = s2 / ((float)(d - 1) * sigma);
+#pragma unroll
+                for (int it = 0; it < MAXIT; ++it) {
+                    const int c = j * 4 + 32 * it;
+                    if (c >= d) continue;
+                    const f32x4 dy = *reinterpret_cast<const f32x4*>(cr + c);
+                    f32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = rstd * (dy[i] * av[it][i] - k1) - k2 * xv[it][i] + rv[it][i];
+                    *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + c) = o;
+                }
+            }
+        } else {
         float s1 = 0.f, s2 = 0.f;
         for (int c = j * 4; c < NP; c += 32) {
             f32x4 g = {0.f, 0.f, 0.f, 0.f}, xh = {0.f, 0.f, 0.f, 0.f};
@@ -351,7 +484,6 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
                     s1 += g[i];
                     s2 += g[i] * xh[i];
                 }
-                // column-sum operands: Fs keeps dy (-> d ln_b), Gs gets dy * xhat (-> d ln_a)
                 f32x4 gx;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) gx[i] = dy[i] * xh[i];
@@ -379,6 +511,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
                 if (p.dres) { f32x4 r = *reinterpret_cast<const f32x4*>(p.dres + (size_t)m * p.lddres + c); o += r; }
                 *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + c) = o;
             }
+        }
         }
         __syncthreads();
         if (p.colpart) {
