@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-model", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dropout as identity (parity-test arithmetic) instead of train mode")
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU number of sequences (experiments only)")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra eager steps with per-kernel HIP-event timing")
     args = ap.parse_args()
 
@@ -193,7 +194,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from multimodal_transformer_amd import _lib
-    cfg = WORKLOADS[args.workload]
+    cfg = dict(WORKLOADS[args.workload])
+    if args.batch > 0:
+        cfg["B"] = args.batch
+        cfg["desc"] += " [batch overridden to %d]" % args.batch
     B, T, d, h, N, f = (cfg[k] for k in ("B", "T", "d", "h", "N", "f"))
     M = B * T
     train = not args.eval_mode

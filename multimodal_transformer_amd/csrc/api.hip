@@ -33,9 +33,9 @@ enum Site { S_PREP = 0, S_LN1_QKV, S_ATTN_FWD, S_OUTPROJ, S_LN2_FFN1, S_FFN2, S_
             S_BWD_OUTPROJ, S_ATTN_BWD, S_DQ_FINISH, S_BWD_QKV_LN1, S_WGRAD, S_FINALIZE, S_OTHER,
             S_LINEAR_FWD, S_LINEAR_BWD_DX, S_LINEAR_WGRAD, S_LSTM_FWD, S_LSTM_BWD, S_MEM_FWD, S_MEM_BWD, S_COUNT };
 static const char* const g_site_names[S_COUNT] = {
-    "encoder_prep_kernel", "rowgemm<FRAG,LN>:ln1+qkv", "attn_fwd_kernel", "rowgemm<PLAIN>:outproj+res",
+    "encoder_prep_kernel", "rowgemm<FRAG,LN>:ln1+qkv", "attn_fwd_kernel", "chain:outproj+res>ln2+ffn1>ffn2+res",
     "rowgemm<PLAIN,LN>:ln2+ffn1+relu", "rowgemm<PLAIN>:ffn2+res", "layernorm_fwd_kernel", "layernorm_bwd_kernel",
-    "rowgemm<PLAIN>:bwd_ffn2", "rowgemm<LNBWD>:bwd_ffn1+ln2", "rowgemm<FRAG>:bwd_outproj->dO", "attn_bwd_dkv_kernel",
+    "chain:bwd_ffn2>bwd_ffn1+ln2>bwd_outproj->dO", "rowgemm<LNBWD>:bwd_ffn1+ln2", "rowgemm<FRAG>:bwd_outproj->dO", "attn_bwd_dkv_kernel",
     "attn_bwd_dq_kernel", "rowgemm<LNBWD>:bwd_qkv+ln1", "wgrad_kernel", "finalize_kernels", "other",
     "rowgemm<PLAIN>:linear_fwd", "rowgemm<PLAIN>:linear_bwd_dx", "wgrad_kernel:linear", "lstm_scan_fwd_kernel", "lstm_scan_bwd_kernel",
     "mfn_mem_scan_fwd_kernel", "mfn_mem_scan_bwd_kernel"};
@@ -201,6 +201,32 @@ static int launch_rowgemm(const RowGemmParams& p, hipStream_t st, int site = S_O
     return MMT_OK;
 }
 
+template <typename K>
+static int launch_rowchain(K kernel, RowChain3& ch, bool with_g, int site, const char* name, hipStream_t st) {
+    // LDS geometry shared by the three stages
+    int kmax = ch.a.KP > ch.b.KP ? ch.a.KP : ch.b.KP;             // stages reading sm.As: a (global) and whichever of b/c stages via Xs
+    if (ch.c.KP > kmax) kmax = ch.c.KP;
+    ch.lda_max = kmax + 8;
+    int fw = 128;
+    if (with_g && ch.b.NP > fw) fw = ch.b.NP;                  // LayerNorm-backward epilogue needs the full row
+    ch.ldf = fw + 4;
+    const size_t lds = rowchain_lds_bytes(ch, with_g);
+    if (lds > 160 * 1024) return fail(MMT_EUNSUPPORTED, "fused row chain needs %zu B of LDS", lds);
+    static const void* configured[4] = {nullptr, nullptr, nullptr, nullptr};     // both chain kernels share this instantiation
+    const void* kp = reinterpret_cast<const void*>(kernel);
+    bool seen = false;
+    for (int i = 0; i < 4; ++i) seen = seen || configured[i] == kp;
+    if (!seen) {
+        HIP_TRY(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int i = 0; i < 4; ++i) if (!configured[i]) { configured[i] = kp; break; }
+    }
+    ProfScope prof(site, st);
+    hipLaunchKernelGGL(kernel, dim3((ch.a.M + 31) / 32), dim3(MMT_THREADS), lds, st, ch);
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) return fail(MMT_EHIP, "launch of %s failed: %s", name, hipGetErrorString(e_));
+    return MMT_OK;
+}
+
 static RowGemmParams rg_zero() { RowGemmParams p; memset(&p, 0, sizeof(p)); p.mask_scale = 1.0f; return p; }
 
 static DropCfg no_drop() { return make_drop(0.f, 0, 0); }
@@ -308,33 +334,28 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
         }
         // dropout streams of layer l: 4l+0 attention probabilities (:33), 4l+1 / 4l+3 sublayer outputs (:104), 4l+2 FFN hidden (:20)
         if ((rc = launch_attn_fwd(L.DKP, w.QR, w.KR, w.VT, w.ctx, w.ctxT, w.lse, D, st, make_drop(dropout_p, seed, 4 * l + 0)))) return rc;
-        {   // output projection + residual
-            RowGemmParams p = rg_zero();
-            p.M = D.M; p.K = L.HDP; p.KP = L.HDP; p.N = d; p.NP = L.DP;
-            p.A = w.ctx; p.a_bf16 = 1; p.lda = L.HDP;
-            p.W = wp + L.pWo(); p.bias = bp + L.qbo();
-            p.residual = xin; p.ldr = d; p.out_f32 = w.x1; p.ldo = d;
-            p.drop = make_drop(dropout_p, seed, 4 * l + 1);
-            if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st, S_OUTPROJ))) return rc;
-        }
-        {   // LayerNorm 2 + first FFN product + ReLU
-            RowGemmParams p = rg_zero();
-            p.M = D.M; p.K = d; p.KP = L.DP; p.N = f; p.NP = L.FP;
-            p.A = w.x1; p.lda = d; p.At_out = w.xn2T; p.ldt = D.MP;
-            p.ln_a = P + L.oln(2); p.ln_b = P + L.oln(3); p.eps = eps; p.stats = w.stats2;
-            p.W = wp + L.pW1(); p.bias = bp + L.qb1(); p.act = 1;
-            p.out_bf16 = w.hid; p.ldo16 = L.FP; p.n_store16 = L.FP; p.out_T = w.hidT; p.ldoT = D.MP;
-            p.drop = make_drop(dropout_p, seed, 4 * l + 2);
-            if ((rc = launch_rowgemm<EPI_PLAIN, true>(p, st, S_LN2_FFN1))) return rc;
-        }
-        {   // second FFN product + residual
-            RowGemmParams p = rg_zero();
-            p.M = D.M; p.K = L.FP; p.KP = L.FP; p.N = d; p.NP = L.DP;
-            p.A = w.hid; p.a_bf16 = 1; p.lda = L.FP;
-            p.W = wp + L.pW2(); p.bias = bp + L.qb2();
-            p.residual = w.x1; p.ldr = d; p.out_f32 = w.xout; p.ldo = d;
-            p.drop = make_drop(dropout_p, seed, 4 * l + 3);
-            if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st, S_FFN2))) return rc;
+        {   // out-proj + residual -> LN2 + FFN1 + ReLU -> FFN2 + residual, one kernel, x1 and hid stay in LDS
+            RowChain3 ch; memset(&ch, 0, sizeof(ch));
+            {   RowGemmParams& p = ch.a; p = rg_zero();
+                p.M = D.M; p.K = L.HDP; p.KP = L.HDP; p.N = d; p.NP = L.DP;
+                p.A = w.ctx; p.a_bf16 = 1; p.lda = L.HDP;
+                p.W = wp + L.pWo(); p.bias = bp + L.qbo();
+                p.residual = xin; p.ldr = d; p.out_f32 = w.x1; p.ldo = d;
+                p.drop = make_drop(dropout_p, seed, 4 * l + 1); }
+            {   RowGemmParams& p = ch.b; p = rg_zero();
+                p.M = D.M; p.K = d; p.KP = L.DP; p.N = f; p.NP = L.FP;
+                p.At_out = w.xn2T; p.ldt = D.MP;
+                p.ln_a = P + L.oln(2); p.ln_b = P + L.oln(3); p.eps = eps; p.stats = w.stats2;
+                p.W = wp + L.pW1(); p.bias = bp + L.qb1(); p.act = 1;
+                p.out_bf16 = w.hid; p.ldo16 = L.FP; p.n_store16 = L.FP; p.out_T = w.hidT; p.ldoT = D.MP;
+                p.drop = make_drop(dropout_p, seed, 4 * l + 2); }
+            {   RowGemmParams& p = ch.c; p = rg_zero();
+                p.M = D.M; p.K = L.FP; p.KP = L.FP; p.N = d; p.NP = L.DP;
+                p.W = wp + L.pW2(); p.bias = bp + L.qb2();
+                p.out_f32 = w.xout; p.ldo = d;
+                p.drop = make_drop(dropout_p, seed, 4 * l + 3); }
+            ch.ldx = L.DP + 4; ch.lda2 = L.FP + 8;
+            if ((rc = launch_rowchain(encoder_post_attn_fwd_kernel, ch, false, S_OUTPROJ, "encoder_post_attn_fwd_kernel", st))) return rc;
         }
         xin = w.xout;
     }
@@ -405,36 +426,31 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
         const float* P = params + (size_t)l * L.stride();
         const bf16* wp = W.wprep + (size_t)l * L.pstride();
         const float* xin = (l > 0) ? W.lw[l - 1].xout : x;
-        {   // dh = (dx2 W2) * relu'(hid)          [also emits dx2^T for dW2]
-            RowGemmParams p = rg_zero();
-            p.M = D.M; p.K = d; p.KP = L.DP; p.N = f; p.NP = L.FP;
-            p.A = cur; p.lda = d; p.At_out = w.dx2T; p.ldt = D.MP;
-            p.W = wp + L.pW2T();
-            p.relu_mask = w.hid; p.ldm = L.FP;          // hid > 0  <=>  ReLU passed AND the unit was kept
-            p.mask_scale = make_drop(dropout_p, seed, 4 * l + 2).scale;
-            p.a_drop = make_drop(dropout_p, seed, 4 * l + 3);   // gradient of the dropped sublayer-1 output
-            p.out_bf16 = W.dh; p.ldo16 = L.FP; p.n_store16 = L.FP; p.out_T = w.dhT; p.ldoT = D.MP;
-            if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st, S_BWD_FFN2))) return rc;
-        }
-        {   // dx1 = dx2 + LN2bwd(dh W1)
-            RowGemmParams p = rg_zero();
-            p.M = D.M; p.K = L.FP; p.KP = L.FP; p.N = d; p.NP = L.DP;
-            p.A = W.dh; p.a_bf16 = 1; p.lda = L.FP;
-            p.W = wp + L.pW1T();
-            p.x = w.x1; p.ldx = d; p.st = w.stats2; p.ln_a = P + L.oln(2); p.eps = eps; p.d_real = d;
-            p.dres = cur; p.lddres = d; p.out_f32 = other; p.ldo = d; p.colpart = w.lnpart2;
-            if ((rc = launch_rowgemm<EPI_LNBWD, false>(p, st, S_BWD_FFN1_LN2))) return rc;
-        }
-        {   // dO = dx1 Wo -> fragments + delta     [also emits dx1^T for dWo]
-            RowGemmParams p = rg_zero();
-            p.M = D.M; p.K = d; p.KP = L.DP; p.N = L.HD; p.NP = L.HDP;
-            p.A = other; p.lda = d; p.At_out = w.dx1T; p.ldt = D.MP;
-            p.W = wp + L.pWoT();
-            p.a_drop = make_drop(dropout_p, seed, 4 * l + 1);   // gradient of the dropped sublayer-0 output
-            p.fragR[0] = W.dOR; p.fragT[0] = W.dOT;
-            p.T = T; p.Tp = D.Tp; p.h = h; p.DKP = L.DKP; p.nwhich = 1;
-            p.ctx = w.ctx; p.ldctx = L.HDP; p.delta = W.delta;
-            if ((rc = launch_rowgemm<EPI_FRAG, false>(p, st, S_BWD_OUTPROJ))) return rc;
+        {   // dx2 -> dh -> dx1 -> dO fragments, one kernel; dh and dx1 stay in LDS
+            RowChain3 ch; memset(&ch, 0, sizeof(ch));
+            {   RowGemmParams& p = ch.a; p = rg_zero();           // dh = (drop'(dx2) W2) * relu'(hid)   [emits dx2^T, dh^T]
+                p.M = D.M; p.K = d; p.KP = L.DP; p.N = f; p.NP = L.FP;
+                p.A = cur; p.lda = d; p.At_out = w.dx2T; p.ldt = D.MP;
+                p.W = wp + L.pW2T();
+                p.relu_mask = w.hid; p.ldm = L.FP;          // hid > 0  <=>  ReLU passed AND the unit was kept
+                p.mask_scale = make_drop(dropout_p, seed, 4 * l + 2).scale;
+                p.a_drop = make_drop(dropout_p, seed, 4 * l + 3);   // gradient of the dropped sublayer-1 output
+                p.out_T = w.dhT; p.ldoT = D.MP; }
+            {   RowGemmParams& p = ch.b; p = rg_zero();           // dx1 = dx2 + LN2bwd(dh W1)
+                p.M = D.M; p.K = L.FP; p.KP = L.FP; p.N = d; p.NP = L.DP;
+                p.W = wp + L.pW1T();
+                p.x = w.x1; p.ldx = d; p.st = w.stats2; p.ln_a = P + L.oln(2); p.eps = eps; p.d_real = d;
+                p.dres = cur; p.lddres = d; p.out_f32 = other; p.ldo = d; p.colpart = w.lnpart2; }
+            {   RowGemmParams& p = ch.c; p = rg_zero();           // dO = drop'(dx1) Wo -> fragments + delta   [emits dx1^T]
+                p.M = D.M; p.K = d; p.KP = L.DP; p.N = L.HD; p.NP = L.HDP;
+                p.At_out = w.dx1T; p.ldt = D.MP;
+                p.W = wp + L.pWoT();
+                p.a_drop = make_drop(dropout_p, seed, 4 * l + 1);   // gradient of the dropped sublayer-0 output
+                p.fragR[0] = W.dOR; p.fragT[0] = W.dOT;
+                p.T = T; p.Tp = D.Tp; p.h = h; p.DKP = L.DKP; p.nwhich = 1;
+                p.ctx = w.ctx; p.ldctx = L.HDP; p.delta = W.delta; }
+            ch.ldx = L.DP + 4; ch.lda2 = L.FP + 8;
+            if ((rc = launch_rowchain(encoder_pre_attn_bwd_kernel, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st))) return rc;
         }
         if ((rc = launch_attn_bwd(L.DKP, w.QR, w.QT, w.KR, w.KT, w.VR, W.dOR, W.dOT, w.lse, W.delta, mask,
                                   W.dqkv, w.dqkvT, D, st, make_drop(dropout_p, seed, 4 * l + 0)))) return rc;

@@ -62,16 +62,23 @@ inline size_t rowgemm_lds_bytes(int EPI, bool lnpro, int KP, int NP) {
     return a + f + g;
 }
 
-template <int EPI, bool LNPRO>
-__global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// A stage = one row-local GEMM with its prologue and epilogue.  Stages can be chained inside one kernel: the
+// 32-window tile then stays in LDS between them (Xs: fp32 tile of the residual stream / a gradient; A2: bf16 tile
+// ready to be the next A operand) instead of making a round trip through L2 and a kernel boundary.
+enum { ASRC_GLOBAL = 0, ASRC_X = 1, ASRC_A2 = 2 };           // where the A operand comes from
+enum { KEEP_X = 1, KEEP_A2 = 2, RES_X = 4 };                  // epilogue: also write fp32 to Xs / bf16 to A2; residual from Xs
+struct RowSmem { bf16* As; float* Fs; float* Gs; float* Xs; bf16* A2; int ldf; int ldx; int lda2; };
+
+template <int EPI, bool LNPRO, int ASRC, int KEEP>
+__device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowSmem& sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int KP = p.KP, NP = p.NP, K = p.K, M = p.M;
-    const int lda_s = KP + 8;                                  // A tile row stride (bf16 elements)
-    const int FW = rowgemm_fw(EPI, LNPRO, KP, NP), ldf = FW + 4;
-    bf16* As = reinterpret_cast<bf16*>(smem);
-    float* Fs = reinterpret_cast<float*>(smem + (size_t)32 * lda_s * 2);
-    float* Gs = Fs + (size_t)32 * ldf;                          // LNBWD only
+    const int lda_s = (ASRC == ASRC_A2) ? sm.lda2 : KP + 8;    // A tile row stride (bf16 elements)
+    const int ldf = sm.ldf;
+    bf16* As = (ASRC == ASRC_A2) ? sm.A2 : sm.As;
+    float* Fs = sm.Fs;
+    float* Gs = sm.Gs;                                         // LNBWD only
+    float* Xs = sm.Xs;
     const int m0 = blockIdx.x * 32;
     const int l15 = lane & 15, lq = lane >> 4;
 
@@ -91,19 +98,23 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
     }
 
     // ------------------------------------------------------------------ 1. A tile -> LDS (bf16)
-    if (LNPRO) {
-        const float* A = static_cast<const float*>(p.A);
-        const int k4 = KP >> 2;
-        for (int idx = tid; idx < 32 * k4; idx += MMT_THREADS) {
-            const int row = idx / k4, c = (idx - row * k4) * 4, m = m0 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < M && c < K) v = *reinterpret_cast<const f32x4*>(A + (size_t)m * p.lda + c);
-            *reinterpret_cast<f32x4*>(Fs + row * ldf + c) = v;
+    if (ASRC == ASRC_A2) {
+        // the previous stage left the bf16 tile in A2 (and ended on a barrier)
+    } else if (LNPRO) {
+        if (ASRC == ASRC_GLOBAL) {
+            const float* A = static_cast<const float*>(p.A);
+            const int k4 = KP >> 2;
+            for (int idx = tid; idx < 32 * k4; idx += MMT_THREADS) {
+                const int row = idx / k4, c = (idx - row * k4) * 4, m = m0 + row;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m < M && c < K) v = *reinterpret_cast<const f32x4*>(A + (size_t)m * p.lda + c);
+                *reinterpret_cast<f32x4*>(Fs + row * ldf + c) = v;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // 8 threads per row; LayerNorm of the reference: unbiased std, eps added to std
         const int row = tid >> 3, j = tid & 7, m = m0 + row;
-        const float* xr = Fs + row * ldf;
+        const float* xr = (ASRC == ASRC_X) ? (Xs + row * sm.ldx) : (Fs + row * ldf);
         float s = 0.f;
         for (int c = j * 4; c < K; c += 32) { f32x4 v = *reinterpret_cast<const f32x4*>(xr + c); s += (v[0] + v[1]) + (v[2] + v[3]); }
         s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
@@ -126,6 +137,26 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
                 f32x4 b = *reinterpret_cast<const f32x4*>(p.ln_b + c);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = (bf16)(a[i] * ((v[i] - mean) * rstd) + b[i]);
+            }
+            *reinterpret_cast<bf16x4*>(As + row * lda_s + c) = o;
+        }
+    } else if (ASRC == ASRC_X) {
+        // fp32 tile kept by the previous stage -> bf16 (optionally through the dropout mask of index m*KP + k)
+        const int k4 = KP >> 2;
+        for (int idx = tid; idx < 32 * k4; idx += MMT_THREADS) {
+            const int row = idx / k4, c = (idx - row * k4) * 4, m = m0 + row;
+            bf16x4 o = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+            if (m < M && c < K) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(Xs + row * sm.ldx + c);
+                if (p.a_drop.thr16) {
+#pragma unroll
+                    for (int i = 0; i < 4; i += 2) {
+                        const uint32_t w = drop_pair(p.a_drop, (uint64_t)m * KP + c + i);
+                        v[i] = drop_lo(p.a_drop, w, v[i]); v[i + 1] = drop_hi(p.a_drop, w, v[i + 1]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (bf16)v[i];
             }
             *reinterpret_cast<bf16x4*>(As + row * lda_s + c) = o;
         }
@@ -245,7 +276,9 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
                 res[it] = f32x4{0.f, 0.f, 0.f, 0.f};
                 rs[it] = 1.f;
                 if (col_ok && m < M) {
-                    if (p.residual) {
+                    if (KEEP & RES_X) {
+                        res[it] = *reinterpret_cast<const f32x4*>(Xs + row * sm.ldx + n);
+                    } else if (p.residual) {
                         if (res_vec) res[it] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.ldr + n);
                         else for (int i = 0; i < 4; ++i) if (n + i < p.N) res[it][i] = p.residual[(size_t)m * p.ldr + n + i];
                     }
@@ -309,6 +342,13 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
                     }
                 }
                 if (p.out_T) *reinterpret_cast<f32x4*>(Fs + row * ldf + cg * 4) = v[it];   // final values for the T pass
+                if (KEEP & KEEP_X) *reinterpret_cast<f32x4*>(Xs + row * sm.ldx + n) = v[it];
+                if (KEEP & KEEP_A2) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (bf16)v[it][i];
+                    *reinterpret_cast<bf16x4*>(sm.A2 + row * sm.lda2 + n) = o;
+                }
             }
             if (p.out_T) {
                 __syncthreads();
@@ -467,6 +507,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[i] = rstd * (dy[i] * av[it][i] - k1) - k2 * xv[it][i] + rv[it][i];
                     *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + c) = o;
+                    if (KEEP & KEEP_X) *reinterpret_cast<f32x4*>(Xs + row * sm.ldx + c) = o;
                 }
             }
         } else {
@@ -510,6 +551,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
                 }
                 if (p.dres) { f32x4 r = *reinterpret_cast<const f32x4*>(p.dres + (size_t)m * p.lddres + c); o += r; }
                 *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + c) = o;
+                if (KEEP & KEEP_X) *reinterpret_cast<f32x4*>(Xs + row * sm.ldx + c) = o;
             }
         }
         }
@@ -523,5 +565,61 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
                 dst[c] = sb; dst[NP + c] = sa;
             }
         }
+        __syncthreads();
     }
+}
+
+// ---- single stage ------------------------------------------------------------------------------
+template <int EPI, bool LNPRO>
+__global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    RowSmem sm;
+    sm.As = reinterpret_cast<bf16*>(smem);
+    sm.Fs = reinterpret_cast<float*>(smem + (size_t)32 * (p.KP + 8) * 2);
+    sm.ldf = rowgemm_fw(EPI, LNPRO, p.KP, p.NP) + 4;
+    sm.Gs = sm.Fs + (size_t)32 * sm.ldf;
+    sm.Xs = nullptr; sm.A2 = nullptr; sm.ldx = 0; sm.lda2 = 0;
+    rowgemm_stage<EPI, LNPRO, ASRC_GLOBAL, 0>(p, sm);
+}
+
+// ---- chained stages ------------------------------------------------------------------------------
+struct RowChain3 { RowGemmParams a, b, c; int lda_max, ldf, ldx, lda2; };   // LDS geometry decided by the host
+
+__host__ __device__ inline size_t rowchain_lds_bytes(const RowChain3& ch, bool with_g) {
+    return (size_t)32 * ch.lda_max * 2 + (size_t)32 * ch.ldf * 4 * (with_g ? 2 : 1) + (size_t)32 * ch.ldx * 4 + (size_t)32 * ch.lda2 * 2;
+}
+__device__ __forceinline__ RowSmem rowchain_carve(char* smem, const RowChain3& ch, bool with_g) {
+    RowSmem sm;
+    sm.As = reinterpret_cast<bf16*>(smem);
+    sm.Fs = reinterpret_cast<float*>(smem + (size_t)32 * ch.lda_max * 2);
+    sm.ldf = ch.ldf;
+    sm.Gs = sm.Fs + (size_t)32 * ch.ldf;
+    sm.Xs = sm.Fs + (size_t)32 * ch.ldf * (with_g ? 2 : 1);
+    sm.ldx = ch.ldx;
+    sm.A2 = reinterpret_cast<bf16*>(sm.Xs + (size_t)32 * ch.ldx);
+    sm.lda2 = ch.lda2;
+    return sm;
+}
+
+// Forward, after the attention core of a layer:   x1 = x + drop(ctx Wo^T + bo)        (out-proj + residual; x1 kept in LDS)
+//                                                 hid = drop(relu(LN2(x1) W1^T + b1))  (hid kept in LDS as the next A tile)
+//                                                 x2 = x1 + drop(hid W2^T + b2)        (residual read from LDS)
+__global__ __launch_bounds__(MMT_THREADS, 2) void encoder_post_attn_fwd_kernel(const RowChain3 ch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const RowSmem sm = rowchain_carve(smem, ch, false);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X>(ch.a, sm);
+    rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2>(ch.b, sm);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X>(ch.c, sm);
+}
+
+// Backward, from the layer-output gradient dx2 down to the attention core's operands:
+//     dh  = (drop'(dx2) W2) * relu'(hid) * drop'          (dh kept in LDS as the next A tile; dx2^T, dh^T emitted for dW)
+//     dx1 = dx2 + LN2bwd(dh W1)                            (kept in LDS)
+//     dO  = drop'(dx1) Wo  -> fragment layouts + delta     (dx1^T emitted for dW)
+__global__ __launch_bounds__(MMT_THREADS, 2) void encoder_pre_attn_bwd_kernel(const RowChain3 ch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const RowSmem sm = rowchain_carve(smem, ch, true);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_A2>(ch.a, sm);
+    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_X>(ch.b, sm);
+    rowgemm_stage<EPI_FRAG, false, ASRC_X, 0>(ch.c, sm);
 }
