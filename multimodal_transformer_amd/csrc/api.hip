@@ -754,17 +754,21 @@ extern "C" int mmt_linear_backward(const float* dy, const float* x, const float*
 
 
 // ------------------------------------------------------------------------------------ LSTM scan
-struct LstmWs { bf16 *Wf, *Wb; int HP16, KP, KP4; size_t bytes; };
+struct LstmWs { bf16 *Wf, *Wb; int HP16, HPAD; size_t bytes; };
 static int carve_lstm(LstmWs& W, int H, void* base) {
     if (H <= 0 || H > 256) return fail(MMT_EUNSUPPORTED, "LSTM hidden size %d not in [4,256]", H);
     if (H % 4) return fail(MMT_EUNSUPPORTED, "LSTM hidden size %d must be a multiple of 4", H);
-    W.HP16 = round_up(H, 16); W.KP = round_up(W.HP16, 32); W.KP4 = 4 * W.HP16;
+    W.HP16 = round_up(H, 16);
+    W.HPAD = W.HP16 <= 64 ? 64 : (W.HP16 <= 128 ? 128 : 256);
     Carver c(base);
-    W.Wf = c.take<bf16>((size_t)4 * W.HP16 * W.KP); W.Wb = c.take<bf16>((size_t)W.HP16 * W.KP4);
+    W.Wf = c.take<bf16>((size_t)4 * W.HP16 * W.HPAD); W.Wb = c.take<bf16>((size_t)W.HP16 * 4 * W.HPAD);
     W.bytes = c.off;
     return MMT_OK;
 }
 extern "C" size_t mmt_lstm_scan_workspace_bytes(int H) { LstmWs W; return carve_lstm(W, H, nullptr) ? 0 : W.bytes; }
+
+// sequences per scan workgroup: the smallest power of two that still fits the batch into <= 256 workgroups (one per CU)
+static int scan_bt(int B) { int bt = 1; while (bt < 16 && (B + bt - 1) / bt > 256) bt *= 2; return bt; }
 
 template <typename K> static int set_lds_attr(K kernel) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -780,14 +784,14 @@ extern "C" int mmt_lstm_scan_forward(const float* gx, const float* W_rec, const 
     if (rc) return rc;
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(lstm_prep_kernel, dim3(grid_for((size_t)8 * W.HP16 * W.KP)), dim3(256), 0, st, W_rec, W.Wf, W.Wb, H, W.HP16, W.KP, W.KP4);
+    hipLaunchKernelGGL(lstm_prep_kernel, dim3(grid_for((size_t)8 * W.HP16 * W.HPAD)), dim3(256), 0, st, W_rec, W.Wf, W.Wb, H, W.HP16, W.HPAD);
     LAUNCH_CHECK("lstm_prep_kernel");
-    const dim3 grid((B + 15) / 16), block(64 * (W.HP16 / 16));
-    const size_t lds = (size_t)2 * 16 * (W.KP + 8) * 2;
+    const int BT = scan_bt(B);
+    const dim3 grid((B + BT - 1) / BT), block(64 * (W.HP16 / 16));
     ProfScope prof(S_LSTM_FWD, st);
-    if (W.HP16 <= 64) hipLaunchKernelGGL((lstm_scan_fwd_kernel<2, 256, true>), grid, block, lds, st, gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, W.KP);
-    else if (W.HP16 <= 128) hipLaunchKernelGGL((lstm_scan_fwd_kernel<4, 512, true>), grid, block, lds, st, gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, W.KP);
-    else hipLaunchKernelGGL((lstm_scan_fwd_kernel<8, 1024, false>), grid, block, lds, st, gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, W.KP);
+    if (W.HPAD == 64) hipLaunchKernelGGL((lstm_scan_fwd_kernel<2, 256, true, 4>), grid, block, 0, st, gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, BT);
+    else if (W.HPAD == 128) hipLaunchKernelGGL((lstm_scan_fwd_kernel<4, 512, true, 4>), grid, block, 0, st, gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, BT);
+    else hipLaunchKernelGGL((lstm_scan_fwd_kernel<8, 1024, false, 1>), grid, block, 0, st, gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, BT);
     LAUNCH_CHECK("lstm_scan_fwd_kernel");
     return MMT_OK;
 }
@@ -801,16 +805,17 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
     if (rc) return rc;
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(lstm_prep_kernel, dim3(grid_for((size_t)8 * W.HP16 * W.KP)), dim3(256), 0, st, W_rec, W.Wf, W.Wb, H, W.HP16, W.KP, W.KP4);
+    hipLaunchKernelGGL(lstm_prep_kernel, dim3(grid_for((size_t)8 * W.HP16 * W.HPAD)), dim3(256), 0, st, W_rec, W.Wf, W.Wb, H, W.HP16, W.HPAD);
     LAUNCH_CHECK("lstm_prep_kernel");
-    const dim3 grid((B + 15) / 16), block(64 * (W.HP16 / 16));
-    const size_t lds = (size_t)2 * 16 * (W.KP4 + 8) * 2;
+    const int BT = scan_bt(B);
+    const dim3 grid((B + BT - 1) / BT), block(64 * (W.HP16 / 16));
+    const size_t lds = (size_t)2 * 16 * (4 * W.HPAD + 8) * 2;
     static bool attr = false;
-    if (!attr) { if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false>))) return rc; attr = true; }
+    if (!attr) { if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false, 1>))) return rc; attr = true; }
     ProfScope prof(S_LSTM_BWD, st);
-    if (W.HP16 <= 64) hipLaunchKernelGGL((lstm_scan_bwd_kernel<8, 256, true>), grid, block, lds, st, dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, W.KP4);
-    else if (W.HP16 <= 128) hipLaunchKernelGGL((lstm_scan_bwd_kernel<16, 512, true>), grid, block, lds, st, dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, W.KP4);
-    else hipLaunchKernelGGL((lstm_scan_bwd_kernel<32, 1024, false>), grid, block, lds, st, dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, W.KP4);
+    if (W.HPAD == 64) hipLaunchKernelGGL((lstm_scan_bwd_kernel<8, 256, true, 2>), grid, block, lds, st, dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, BT);
+    else if (W.HPAD == 128) hipLaunchKernelGGL((lstm_scan_bwd_kernel<16, 512, true, 2>), grid, block, lds, st, dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, BT);
+    else hipLaunchKernelGGL((lstm_scan_bwd_kernel<32, 1024, false, 1>), grid, block, lds, st, dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, BT);
     LAUNCH_CHECK("lstm_scan_bwd_kernel");
     return MMT_OK;
 }
@@ -844,7 +849,7 @@ extern "C" int mmt_mfn_mem_scan_forward(const float* apre, const float* chat, co
     hipLaunchKernelGGL(mfn_prep_kernel, dim3(64), dim3(256), 0, st, Wm, W2, W.WmF, W.W2F, W.WmB, W.W2B);
     LAUNCH_CHECK("mfn_prep_kernel");
     ProfScope prof(S_MEM_FWD, st);
-    hipLaunchKernelGGL(mfn_mem_scan_fwd_kernel, dim3((B + 15) / 16), dim3(512), 0, st, apre, chat, W.WmF, W.W2F, b2, mem_all, u_all, g_all, T, B,
+    hipLaunchKernelGGL(mfn_mem_scan_fwd_kernel, dim3((B + scan_bt(B) - 1) / scan_bt(B)), dim3(512), 0, st, apre, chat, W.WmF, W.W2F, b2, mem_all, u_all, g_all, T, B, scan_bt(B),
                        make_drop(dropout_p, seed, 1000));
     LAUNCH_CHECK("mfn_mem_scan_fwd_kernel");
     return MMT_OK;
@@ -864,8 +869,8 @@ extern "C" int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* cha
     hipLaunchKernelGGL(mfn_prep_kernel, dim3(64), dim3(256), 0, st, Wm, W2, W.WmF, W.W2F, W.WmB, W.W2B);
     LAUNCH_CHECK("mfn_prep_kernel");
     ProfScope prof(S_MEM_BWD, st);
-    hipLaunchKernelGGL(mfn_mem_scan_bwd_kernel, dim3((B + 15) / 16), dim3(512), 0, st, dmem_all, chat, mem_all, u_all, g_all, W.WmB, W.W2B,
-                       dchat, dapre, dz_all, T, B, make_drop(dropout_p, 0, 0).scale);
+    hipLaunchKernelGGL(mfn_mem_scan_bwd_kernel, dim3((B + scan_bt(B) - 1) / scan_bt(B)), dim3(512), 0, st, dmem_all, chat, mem_all, u_all, g_all, W.WmB, W.W2B,
+                       dchat, dapre, dz_all, T, B, scan_bt(B), make_drop(dropout_p, 0, 0).scale);
     LAUNCH_CHECK("mfn_mem_scan_bwd_kernel");
     return MMT_OK;
 }

@@ -10,55 +10,62 @@
 #pragma once
 #include "common.h"
 
+// Workgroup barrier for the scans: waits for this wave's LDS traffic only.  __syncthreads() would also drain vmcnt(0),
+// i.e. wait at EVERY time step for the prefetched inputs of later steps and for the step's output stores
+// (cdna_hip_programming.md §5 "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp2(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float tanh_f(float x) { return 2.0f * sigmoid_f(2.0f * x) - 1.0f; }
 
-// W_rec (4H,H) fp32 -> forward operand Wf bf16 [4][HP16][KP] (Wf[q][j][k] = W[q*H+j][k]) and
-// backward operand Wb bf16 [HP16][KP4] (Wb[j][q*HP16+j'] = W[q*H+j'][j]); zero padded.
+// W_rec (4H,H) fp32 -> forward operand Wf bf16 [4][HP16][HPAD] (Wf[q][j][k] = W[q*H+j][k]) and
+// backward operand Wb bf16 [HP16][4*HPAD] (Wb[j][q*HPAD+j'] = W[q*H+j'][j]); zero padded.
+// HPAD = hidden size padded to 64 / 128 / 256: every loop bound in the scans is then a compile-time constant.
 __global__ void lstm_prep_kernel(const float* __restrict__ W, bf16* __restrict__ Wf, bf16* __restrict__ Wb,
-                                 int H, int HP16, int KP, int KP4) {
-    const size_t nf = (size_t)4 * HP16 * KP, nb = (size_t)HP16 * KP4;
+                                 int H, int HP16, int HPAD) {
+    const size_t nf = (size_t)4 * HP16 * HPAD, nb = (size_t)HP16 * 4 * HPAD;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nf + nb; idx += (size_t)gridDim.x * blockDim.x) {
         if (idx < nf) {
-            const int k = (int)(idx % KP), j = (int)((idx / KP) % HP16), q = (int)(idx / ((size_t)KP * HP16));
+            const int k = (int)(idx % HPAD), j = (int)((idx / HPAD) % HP16), q = (int)(idx / ((size_t)HPAD * HP16));
             Wf[idx] = (bf16)((j < H && k < H) ? W[((size_t)q * H + j) * H + k] : 0.f);
         } else {
             const size_t i = idx - nf;
-            const int c = (int)(i % KP4), j = (int)(i / KP4);
-            float v = 0.f;
-            if (c < 4 * HP16) { const int q = c / HP16, jp = c - q * HP16; if (j < H && jp < H) v = W[((size_t)q * H + jp) * H + j]; }
-            Wb[i] = (bf16)v;
+            const int c = (int)(i % (4 * HPAD)), j = (int)(i / (4 * HPAD));
+            const int q = c / HPAD, jp = c - q * HPAD;
+            Wb[i] = (bf16)((j < H && jp < H) ? W[((size_t)q * H + jp) * H + j] : 0.f);
         }
     }
 }
 
-// grid = ceil(B/16); block = 64 * (HP16/16) <= NT.  MAXKS >= KP/32.  WREG: W_rec fragments stay in registers
-// for the whole scan (HP16 <= 128); otherwise (HP16 = 256: 512 KB of bf16 weights exceed one CU's register
-// file) they are re-streamed from L2 every step.
-template <int MAXKS, int NT, bool WREG>
+// grid = ceil(B/16); block = 64 * (HP16/16) <= NT.  HPAD = 32*KS.  WREG: W_rec fragments stay in registers for the
+// whole scan (HPAD <= 128); otherwise (HPAD = 256: 512 KB of bf16 weights exceed one CU's register file) they are
+// re-streamed from L2 every step.  The time loop is straight-line code: lanes outside the batch / hidden range
+// compute on clamped addresses and simply do not store.
+template <int KS, int NT, bool WREG, int PF>
 __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restrict__ gx, const bf16* __restrict__ Wf,
                                      const float* __restrict__ h0, const float* __restrict__ c0,
                                      float* __restrict__ h_all, float* __restrict__ c_all, float* __restrict__ acts,
-                                     int T, int B, int H, int HP16, int KP) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ldh = KP + 8;
-    bf16* hbuf = reinterpret_cast<bf16*>(smem);                 // [2][16][ldh]
+                                     int T, int B, int H, int HP16, int BT) {
+    constexpr int KP = 32 * KS, ldh = KP + 8;
+    __shared__ __attribute__((aligned(16))) bf16 hbuf[2 * 16 * ldh];
     const int lane = threadIdx.x & 63, jt = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
-    const int nks = KP >> 5;
-    const int b = blockIdx.x * 16 + l15, j0 = jt * 16 + 4 * lq;
-    const bool live = (b < B) && (j0 < H);                      // H % 4 == 0: the 4 rows of a lane are all in or all out
+    // BT <= 16 sequences per workgroup: the scan is latency-bound and its per-step traffic must not funnel through a
+    // couple of CUs, so small batches are spread over many workgroups and the unused MFMA columns simply idle.
+    const int b = blockIdx.x * BT + l15, j0 = jt * 16 + 4 * lq;
+    const bool live = (l15 < BT) && (b < B) && (j0 < H);        // H % 4 == 0: the 4 rows of a lane are all in or all out
+    const int bc = b < B ? b : B - 1, jc = j0 < H ? j0 : H - 4; // clamped (always valid) coordinates for loads
 
     const bf16* wrow = Wf + (size_t)(jt * 16 + l15) * KP + 8 * lq;      // + q*HP16*KP + ks*32
     const size_t wq = (size_t)HP16 * KP;
-    bf16x8 a[WREG ? 4 : 1][WREG ? MAXKS : 1];
+    bf16x8 a[WREG ? 4 : 1][WREG ? KS : 1];
     if (WREG) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int ks = 0; ks < MAXKS; ++ks)
-                if (ks < nks) a[q][ks] = *reinterpret_cast<const bf16x8*>(wrow + q * wq + ks * 32);
+            for (int ks = 0; ks < KS; ++ks) a[q][ks] = *reinterpret_cast<const bf16x8*>(wrow + q * wq + ks * 32);
     }
-
     for (int i = threadIdx.x; i < 2 * 16 * ldh; i += blockDim.x) hbuf[i] = (bf16)0.f;
     __syncthreads();
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
@@ -72,32 +79,34 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
     }
     __syncthreads();
 
-    f32x4 nxt[4];
+    const float* gxl = gx + (size_t)bc * 4 * H + jc;             // + t*B*4H + q*H
+    const size_t gstep = (size_t)B * 4 * H;
+    // input projections of the next PF steps are always in flight (register ring, statically indexed by unrolling)
+    f32x4 ring[PF][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        nxt[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (live) nxt[q] = *reinterpret_cast<const f32x4*>(gx + ((size_t)0 * B + b) * 4 * H + (size_t)q * H + j0);
+    for (int d = 0; d < PF; ++d) {
+        const int tl = d < T ? d : T - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ring[d][q] = *reinterpret_cast<const f32x4*>(gxl + tl * gstep + (size_t)q * H);
     }
     int cur = 0;
-    for (int t = 0; t < T; ++t) {
+    auto step = [&](int t, f32x4 (&in)[4]) {
         f32x4 acc[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = nxt[q];
-        if (t + 1 < T && live) {                                // next step's input projection in flight behind this step
+        for (int q = 0; q < 4; ++q) acc[q] = in[q];
+        {
+            const int tn = (t + PF < T) ? t + PF : T - 1;       // clamped: the tail re-reads the last step (unused)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                nxt[q] = *reinterpret_cast<const f32x4*>(gx + ((size_t)(t + 1) * B + b) * 4 * H + (size_t)q * H + j0);
+            for (int q = 0; q < 4; ++q) in[q] = *reinterpret_cast<const f32x4*>(gxl + tn * gstep + (size_t)q * H);
         }
         const bf16* hb = hbuf + cur * 16 * ldh + l15 * ldh + 8 * lq;
 #pragma unroll
-        for (int ks = 0; ks < MAXKS; ++ks) {
-            if (ks < nks) {
-                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(hb + ks * 32);
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(hb + ks * 32);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bf16x8 af = WREG ? a[WREG ? q : 0][WREG ? ks : 0] : *reinterpret_cast<const bf16x8*>(wrow + q * wq + ks * 32);
-                    acc[q] = mfma16(af, bf, acc[q]);
-                }
+            for (int q = 0; q < 4; ++q) {
+                const bf16x8 af = WREG ? a[WREG ? q : 0][WREG ? ks : 0] : *reinterpret_cast<const bf16x8*>(wrow + q * wq + ks * 32);
+                acc[q] = mfma16(af, bf, acc[q]);
             }
         }
         f32x4 ig, fg, gg, og, hn;
@@ -105,9 +114,13 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
         for (int r = 0; r < 4; ++r) {
             ig[r] = sigmoid_f(acc[0][r]); fg[r] = sigmoid_f(acc[1][r]); gg[r] = tanh_f(acc[2][r]); og[r] = sigmoid_f(acc[3][r]);
             c[r] = fg[r] * c[r] + ig[r] * gg[r];
-            hn[r] = og[r] * tanh_f(c[r]);
+            hn[r] = live ? og[r] * tanh_f(c[r]) : 0.f;          // pad lanes keep h = 0 in LDS
         }
-        bf16* hw = hbuf + (cur ^ 1) * 16 * ldh + l15 * ldh + j0;
+        bf16x4 hb4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hb4[r] = (bf16)hn[r];
+        *reinterpret_cast<bf16x4*>(hbuf + (cur ^ 1) * 16 * ldh + l15 * ldh + jt * 16 + 4 * lq) = hb4;
+        lds_barrier();                                          // h_t visible to every wave; global traffic stays in flight
         if (live) {
             const size_t o = ((size_t)t * B + b) * H + j0;
             *reinterpret_cast<f32x4*>(h_all + o) = hn;
@@ -115,95 +128,127 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
             float* ap = acts + ((size_t)t * B + b) * 4 * H + j0;
             *reinterpret_cast<f32x4*>(ap) = ig; *reinterpret_cast<f32x4*>(ap + H) = fg;
             *reinterpret_cast<f32x4*>(ap + 2 * H) = gg; *reinterpret_cast<f32x4*>(ap + 3 * H) = og;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hw[r] = (bf16)hn[r];
         }
-        __syncthreads();
         cur ^= 1;
+    };
+    int t0 = 0;
+    for (; t0 + PF <= T; t0 += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) step(t0 + d, ring[d]);
     }
+#pragma unroll
+    for (int d = 0; d < PF; ++d) if (t0 + d < T) step(t0 + d, ring[d]);
 }
 
 // Backward through time.  dG[t] (gate pre-activation gradients, fp32 (T,B,4H)) is also what the batched
-// input-projection / weight gradients consume afterwards.  MAXKS >= KP4/32.
-template <int MAXKS, int NT, bool WREG>
+// input-projection / weight gradients consume afterwards.  KS4 = 4*HPAD/32.
+template <int KS4, int NT, bool WREG, int PF>
 __global__ __launch_bounds__(NT) void lstm_scan_bwd_kernel(const float* __restrict__ dh_ext, const float* __restrict__ dc_ext,
                                      const bf16* __restrict__ Wb, const float* __restrict__ c0,
                                      const float* __restrict__ c_all, const float* __restrict__ acts,
                                      float* __restrict__ dG, float* __restrict__ dh0, float* __restrict__ dc0,
-                                     int T, int B, int H, int HP16, int KP4) {
+                                     int T, int B, int H, int HP16, int BT) {
+    constexpr int KP4 = 32 * KS4, HPAD = KP4 / 4, ldg = KP4 + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int ldg = KP4 + 8;
     bf16* gbuf = reinterpret_cast<bf16*>(smem);                 // [2][16][ldg]
     const int lane = threadIdx.x & 63, jt = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
-    const int nks = KP4 >> 5;
-    const int b = blockIdx.x * 16 + l15, j0 = jt * 16 + 4 * lq;
-    const bool live = (b < B) && (j0 < H);
+    const int b = blockIdx.x * BT + l15, j0 = jt * 16 + 4 * lq;
+    const bool live = (l15 < BT) && (b < B) && (j0 < H);
+    const int bc = b < B ? b : B - 1, jc = j0 < H ? j0 : H - 4;
+    const float lv = live ? 1.f : 0.f;
 
     const bf16* wrow = Wb + (size_t)(jt * 16 + l15) * KP4 + 8 * lq;
-    bf16x8 a[WREG ? MAXKS : 1];
+    bf16x8 a[WREG ? KS4 : 1];
     if (WREG) {
 #pragma unroll
-        for (int ks = 0; ks < MAXKS; ++ks)
-            if (ks < nks) a[ks] = *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
+        for (int ks = 0; ks < KS4; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
     }
     for (int i = threadIdx.x; i < 2 * 16 * ldg; i += blockDim.x) gbuf[i] = (bf16)0.f;
     __syncthreads();
 
     f32x4 dh_rec = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};
-    int cur = 0;
-    for (int t = T - 1; t >= 0; --t) {
-        f32x4 dgi = {0.f, 0.f, 0.f, 0.f}, dgf = dgi, dgg = dgi, dgo = dgi;
-        if (live) {
-            const size_t o = ((size_t)t * B + b) * H + j0;
-            const float* ap = acts + ((size_t)t * B + b) * 4 * H + j0;
-            const f32x4 ig = *reinterpret_cast<const f32x4*>(ap), fg = *reinterpret_cast<const f32x4*>(ap + H);
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(ap + 2 * H), og = *reinterpret_cast<const f32x4*>(ap + 3 * H);
-            const f32x4 ct = *reinterpret_cast<const f32x4*>(c_all + o);
-            f32x4 cp = {0.f, 0.f, 0.f, 0.f};
-            if (t > 0) cp = *reinterpret_cast<const f32x4*>(c_all + o - (size_t)B * H);
-            else if (c0) cp = *reinterpret_cast<const f32x4*>(c0 + (size_t)b * H + j0);
-            f32x4 dh = dh_rec;
-            if (dh_ext) dh += *reinterpret_cast<const f32x4*>(dh_ext + o);
-            if (dc_ext) dc += *reinterpret_cast<const f32x4*>(dc_ext + o);
+    // saved activations / cell states / external gradients of the next PF steps (going backwards) stay in flight
+    struct StepIn { f32x4 ig, fg, gg, og, ct, cp, dhe, dce; };
+    StepIn ring[PF];
+    const size_t ostep = (size_t)B * H;
+    const float* actl = acts + (size_t)bc * 4 * H + jc;
+    const float* cl = c_all + (size_t)bc * H + jc;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 c0v = zero4;
+    if (c0) c0v = *reinterpret_cast<const f32x4*>(c0 + (size_t)bc * H + jc);
+    auto fetch = [&](StepIn& r, int t) {
+        const int tc = t > 0 ? t : 0;                           // clamped, branch-free
+        const float* ap = actl + (size_t)tc * ostep * 4;
+        r.ig = *reinterpret_cast<const f32x4*>(ap); r.fg = *reinterpret_cast<const f32x4*>(ap + H);
+        r.gg = *reinterpret_cast<const f32x4*>(ap + 2 * H); r.og = *reinterpret_cast<const f32x4*>(ap + 3 * H);
+        r.ct = *reinterpret_cast<const f32x4*>(cl + (size_t)tc * ostep);
+        r.cp = *reinterpret_cast<const f32x4*>(cl + (size_t)(tc > 0 ? tc - 1 : 0) * ostep);
+        if (t <= 0) r.cp = c0v;
+        r.dhe = dh_ext ? *reinterpret_cast<const f32x4*>(dh_ext + (size_t)bc * H + jc + (size_t)tc * ostep) : zero4;
+        r.dce = dc_ext ? *reinterpret_cast<const f32x4*>(dc_ext + (size_t)bc * H + jc + (size_t)tc * ostep) : zero4;
+    };
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float th = tanh_f(ct[r]);
-                const float dct = dc[r] + dh[r] * og[r] * (1.f - th * th);
-                dgo[r] = dh[r] * th * og[r] * (1.f - og[r]);
-                dgi[r] = dct * gg[r] * ig[r] * (1.f - ig[r]);
-                dgf[r] = dct * cp[r] * fg[r] * (1.f - fg[r]);
-                dgg[r] = dct * ig[r] * (1.f - gg[r] * gg[r]);
-                dc[r] = dct * fg[r];
-            }
+    for (int d = 0; d < PF; ++d) fetch(ring[d], T - 1 - d);
+    int cur = 0;
+    auto step = [&](int t, StepIn& slot) {
+        const StepIn in = slot;
+        fetch(slot, t - PF);
+        f32x4 dgi, dgf, dgg, dgo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dh = dh_rec[r] + in.dhe[r];
+            const float th = tanh_f(in.ct[r]);
+            const float dct = dc[r] + in.dce[r] + dh * in.og[r] * (1.f - th * th);
+            dgo[r] = lv * dh * th * in.og[r] * (1.f - in.og[r]);
+            dgi[r] = lv * dct * in.gg[r] * in.ig[r] * (1.f - in.ig[r]);
+            dgf[r] = lv * dct * in.cp[r] * in.fg[r] * (1.f - in.fg[r]);
+            dgg[r] = lv * dct * in.ig[r] * (1.f - in.gg[r] * in.gg[r]);
+            dc[r] = dct * in.fg[r];
+        }
+        bf16* gw = gbuf + cur * 16 * ldg + l15 * ldg + jt * 16 + 4 * lq;
+        bf16x4 p0, p1, p2, p3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p0[r] = (bf16)dgi[r]; p1[r] = (bf16)dgf[r]; p2[r] = (bf16)dgg[r]; p3[r] = (bf16)dgo[r]; }
+        *reinterpret_cast<bf16x4*>(gw) = p0; *reinterpret_cast<bf16x4*>(gw + HPAD) = p1;
+        *reinterpret_cast<bf16x4*>(gw + 2 * HPAD) = p2; *reinterpret_cast<bf16x4*>(gw + 3 * HPAD) = p3;
+        lds_barrier();
+        if (live) {
             float* gp = dG + ((size_t)t * B + b) * 4 * H + j0;
             *reinterpret_cast<f32x4*>(gp) = dgi; *reinterpret_cast<f32x4*>(gp + H) = dgf;
             *reinterpret_cast<f32x4*>(gp + 2 * H) = dgg; *reinterpret_cast<f32x4*>(gp + 3 * H) = dgo;
         }
-        bf16* gw = gbuf + cur * 16 * ldg + l15 * ldg + j0;
-        if (j0 < HP16) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                gw[r] = (bf16)dgi[r]; gw[HP16 + r] = (bf16)dgf[r]; gw[2 * HP16 + r] = (bf16)dgg[r]; gw[3 * HP16 + r] = (bf16)dgo[r];
-            }
-        }
-        __syncthreads();
         const bf16* gb = gbuf + cur * 16 * ldg + l15 * ldg + 8 * lq;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // four independent accumulation chains (one per gate block of the contraction): a single chain of KS4
+        // dependent MFMAs would serialise on the accumulator latency
+        f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        // the B operand (all 4H gate gradients of a sequence) is the LDS-bandwidth term of a step: 16 KB per wave
+        // at H = 128.  Only the BT live MFMA columns are read; the other lanes keep whatever their registers
+        // held (a column of D depends on the same column of B only, and dead columns are never stored).
+        bf16x8 bfr[KS4];
+        if (l15 < BT) {
 #pragma unroll
-        for (int ks = 0; ks < MAXKS; ++ks)
-            if (ks < nks) {
-                const bf16x8 af = WREG ? a[WREG ? ks : 0] : *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
-                acc = mfma16(af, *reinterpret_cast<const bf16x8*>(gb + ks * 32), acc);
-            }
-        dh_rec = acc;
+            for (int ks = 0; ks < KS4; ++ks) bfr[ks] = *reinterpret_cast<const bf16x8*>(gb + ks * 32);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS4; ++ks) {
+            const bf16x8 af = WREG ? a[WREG ? ks : 0] : *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
+            acc[ks & 3] = mfma16(af, bfr[ks], acc[ks & 3]);
+        }
+        dh_rec = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         cur ^= 1;
+    };
+    int tb = T - 1;
+    for (; tb - PF + 1 >= 0; tb -= PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) step(tb - d, ring[d]);
     }
+#pragma unroll
+    for (int d = 0; d < PF; ++d) if (tb - d >= 0) step(tb - d, ring[d]);
     if (live) {
         if (dh0) *reinterpret_cast<f32x4*>(dh0 + (size_t)b * H + j0) = dh_rec;
         if (dc0) *reinterpret_cast<f32x4*>(dc0 + (size_t)b * H + j0) = dc;
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // MFN delta-memory recurrence (transformer/MFT/multiTransformer.py:221-224), mem_dim = 128 (:133),
@@ -236,13 +281,13 @@ __global__ void mfn_prep_kernel(const float* __restrict__ Wm, const float* __res
 __global__ __launch_bounds__(512) void mfn_mem_scan_fwd_kernel(
         const float* __restrict__ apre, const float* __restrict__ chat, const bf16* __restrict__ WmF,
         const bf16* __restrict__ W2F, const float* __restrict__ b2,
-        float* __restrict__ mem_all, float* __restrict__ u_all, float* __restrict__ g_all, int T, int B, DropCfg drop) {
+        float* __restrict__ mem_all, float* __restrict__ u_all, float* __restrict__ g_all, int T, int B, int BT, DropCfg drop) {
     __shared__ __attribute__((aligned(16))) bf16 membuf[16 * (MFN_MD + 8)];
     __shared__ __attribute__((aligned(16))) bf16 ubuf[16 * (MFN_U + 8)];
     constexpr int LDM = MFN_MD + 8, LDU = MFN_U + 8;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
-    const int b = blockIdx.x * 16 + l15, j0 = w * 16 + 4 * lq;
-    const bool live = b < B;
+    const int b = blockIdx.x * BT + l15, j0 = w * 16 + 4 * lq;
+    const bool live = (l15 < BT) && (b < B);
     bf16x8 am[4], a1[2], a2[2];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) am[ks] = *reinterpret_cast<const bf16x8*>(WmF + (size_t)(w * 16 + l15) * MFN_MD + ks * 32 + 8 * lq);
@@ -277,7 +322,7 @@ __global__ __launch_bounds__(512) void mfn_mem_scan_fwd_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) ubuf[l15 * LDU + j0 + r] = (bf16)acc[r];
         }
-        __syncthreads();
+        lds_barrier();
         f32x4 z1 = bias1, z2 = bias2;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -293,7 +338,7 @@ __global__ __launch_bounds__(512) void mfn_mem_scan_fwd_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) membuf[l15 * LDM + j0 + r] = (bf16)mem[r];
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -302,13 +347,13 @@ __global__ __launch_bounds__(512) void mfn_mem_scan_fwd_kernel(
 __global__ __launch_bounds__(512) void mfn_mem_scan_bwd_kernel(
         const float* __restrict__ dmem_ext, const float* __restrict__ chat, const float* __restrict__ mem_all,
         const float* __restrict__ u_all, const float* __restrict__ g_all, const bf16* __restrict__ WmB, const bf16* __restrict__ W2B,
-        float* __restrict__ dchat, float* __restrict__ dapre, float* __restrict__ dz_all, int T, int B, float drop_scale) {
+        float* __restrict__ dchat, float* __restrict__ dapre, float* __restrict__ dz_all, int T, int B, int BT, float drop_scale) {
     __shared__ __attribute__((aligned(16))) bf16 zbuf[16 * (2 * MFN_MD + 8)];
     __shared__ __attribute__((aligned(16))) bf16 pbuf[16 * (MFN_U + 8)];
     constexpr int LDZ = 2 * MFN_MD + 8, LDP = MFN_U + 8;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
-    const int b = blockIdx.x * 16 + l15, j0 = w * 16 + 4 * lq;
-    const bool live = b < B;
+    const int b = blockIdx.x * BT + l15, j0 = w * 16 + 4 * lq;
+    const bool live = (l15 < BT) && (b < B);
     const int gsel = (w * 16) / MFN_HG;                         // which gate MLP this wave's u rows belong to
     bf16x8 a2[4], am[4];
 #pragma unroll
@@ -346,7 +391,7 @@ __global__ __launch_bounds__(512) void mfn_mem_scan_bwd_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) { zbuf[l15 * LDZ + j0 + r] = (bf16)dz1[r]; zbuf[l15 * LDZ + MFN_MD + j0 + r] = (bf16)dz2[r]; }
         }
-        __syncthreads();
+        lds_barrier();
         // du rows [16w,16w+16) = W2_g^T dz_g ;  dpre = du * relu'(u)
         f32x4 du = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -359,7 +404,7 @@ __global__ __launch_bounds__(512) void mfn_mem_scan_bwd_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) pbuf[l15 * LDP + j0 + r] = (bf16)du[r];
         }
-        __syncthreads();
+        lds_barrier();
         f32x4 rec = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
