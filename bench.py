@@ -45,20 +45,23 @@ def flops_per_window_layer_fwd(d, T, f):
     return 8 * d * d + 4 * T * d + 4 * d * f
 
 
-def site_flops_per_launch(site, M, T, d, f):
+def site_flops_per_launch(site, M, T, d, f, n_layers=1):
     """Algorithmic FLOPs of one launch of a kernel site (no credit for recomputation)."""
     table = {
         "rowgemm<FRAG,LN>:ln1+qkv": 6 * d * d,
-        "attn_fwd_kernel": 4 * T * d,
+        "attn_fwd_kernel": 4 * T * d,                                   # QK^T and PV
+        "chain:outproj+res>ln2+ffn1>ffn2+res": 2 * d * d + 4 * d * f,
+        "chain:bwd_ffn2>bwd_ffn1+ln2>bwd_outproj->dO": 4 * d * f + 2 * d * d,
+        "attn_bwd_dkv_kernel": 6 * T * d,                               # dV, dP, dK  (S recomputed: no credit)
+        "attn_bwd_dq_kernel": 2 * T * d,                                # dQ          (S, dP recomputed: no credit)
+        "rowgemm<LNBWD>:bwd_qkv+ln1": 6 * d * d,
+        "wgrad_kernel": (8 * d * d + 4 * d * f) * n_layers,             # one launch covers every layer
         "rowgemm<PLAIN>:outproj+res": 2 * d * d,
         "rowgemm<PLAIN,LN>:ln2+ffn1+relu": 2 * d * f,
         "rowgemm<PLAIN>:ffn2+res": 2 * d * f,
         "rowgemm<PLAIN>:bwd_ffn2": 2 * d * f,
         "rowgemm<LNBWD>:bwd_ffn1+ln2": 2 * d * f,
         "rowgemm<FRAG>:bwd_outproj->dO": 2 * d * d,
-        "attn_bwd_kernel": 8 * T * d,
-        "rowgemm<LNBWD>:bwd_qkv+ln1": 6 * d * d,
-        "wgrad_kernel": 8 * d * d + 4 * d * f,
     }
     return table.get(site, 0) * M
 
@@ -234,7 +237,7 @@ def main():
         kernel_ms = {k: round(v[0] / args.profile_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         name, (tot_ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
         avg_s = tot_ms / cnt * 1e-3
-        fl = site_flops_per_launch(name, M, T, d, f)
+        fl = site_flops_per_launch(name, M, T, d, f, N)
         ach = fl / avg_s / 1e12 if avg_s > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": None,
