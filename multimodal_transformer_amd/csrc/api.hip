@@ -789,9 +789,18 @@ extern "C" int mmt_lstm_scan_forward(const float* gx, const float* W_rec, const 
     const int BT = scan_bt(B);
     const dim3 grid((B + BT - 1) / BT), block(64 * (W.HP16 / 16));
     ProfScope prof(S_LSTM_FWD, st);
-    if (W.HPAD == 64) hipLaunchKernelGGL((lstm_scan_fwd_kernel<2, 256, true, 4>), grid, block, 0, st, gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, BT);
-    else if (W.HPAD == 128) hipLaunchKernelGGL((lstm_scan_fwd_kernel<4, 512, true, 4>), grid, block, 0, st, gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, BT);
-    else hipLaunchKernelGGL((lstm_scan_fwd_kernel<8, 1024, false, 1>), grid, block, 0, st, gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, BT);
+#define MMT_LSTM_FWD(KS, NT, WREG, PF, COOP) hipLaunchKernelGGL((lstm_scan_fwd_kernel<KS, NT, WREG, PF, COOP>), grid, block, 0, st, \
+        gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, BT)
+    if (BT <= 2) {              // cooperative step-input loader (see scan.h)
+        if (W.HPAD == 64) MMT_LSTM_FWD(2, 256, true, 4, true);
+        else if (W.HPAD == 128) MMT_LSTM_FWD(4, 512, true, 4, true);
+        else MMT_LSTM_FWD(8, 1024, false, 1, true);
+    } else {
+        if (W.HPAD == 64) MMT_LSTM_FWD(2, 256, true, 4, false);
+        else if (W.HPAD == 128) MMT_LSTM_FWD(4, 512, true, 2, false);
+        else MMT_LSTM_FWD(8, 1024, false, 1, false);
+    }
+#undef MMT_LSTM_FWD
     LAUNCH_CHECK("lstm_scan_fwd_kernel");
     return MMT_OK;
 }
@@ -809,13 +818,27 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
     LAUNCH_CHECK("lstm_prep_kernel");
     const int BT = scan_bt(B);
     const dim3 grid((B + BT - 1) / BT), block(64 * (W.HP16 / 16));
-    const size_t lds = (size_t)2 * 16 * (4 * W.HPAD + 8) * 2;
+    const bool coop = BT <= 2;
+    const size_t lds = (size_t)2 * 16 * (4 * W.HPAD + 8) * 2 + (coop ? ((size_t)2 * 2 * 8 * W.HPAD + 64 * (W.HP16 / 16)) * sizeof(float) : 0);
     static bool attr = false;
-    if (!attr) { if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false, 1>))) return rc; attr = true; }
+    if (!attr) {
+        if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false, 1, false>))) return rc;
+        if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false, 2, true>))) return rc;
+        attr = true;
+    }
     ProfScope prof(S_LSTM_BWD, st);
-    if (W.HPAD == 64) hipLaunchKernelGGL((lstm_scan_bwd_kernel<8, 256, true, 2>), grid, block, lds, st, dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, BT);
-    else if (W.HPAD == 128) hipLaunchKernelGGL((lstm_scan_bwd_kernel<16, 512, true, 2>), grid, block, lds, st, dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, BT);
-    else hipLaunchKernelGGL((lstm_scan_bwd_kernel<32, 1024, false, 1>), grid, block, lds, st, dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, BT);
+#define MMT_LSTM_BWD(KS4, NT, WREG, PF, COOP) hipLaunchKernelGGL((lstm_scan_bwd_kernel<KS4, NT, WREG, PF, COOP>), grid, block, lds, st, \
+        dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, BT)
+    if (coop) {
+        if (W.HPAD == 64) MMT_LSTM_BWD(8, 256, true, 4, true);
+        else if (W.HPAD == 128) MMT_LSTM_BWD(16, 512, true, 4, true);
+        else MMT_LSTM_BWD(32, 1024, false, 2, true);
+    } else {
+        if (W.HPAD == 64) MMT_LSTM_BWD(8, 256, true, 2, false);
+        else if (W.HPAD == 128) MMT_LSTM_BWD(16, 512, true, 2, false);
+        else MMT_LSTM_BWD(32, 1024, false, 1, false);
+    }
+#undef MMT_LSTM_BWD
     LAUNCH_CHECK("lstm_scan_bwd_kernel");
     return MMT_OK;
 }

@@ -43,7 +43,11 @@ __global__ void lstm_prep_kernel(const float* __restrict__ W, bf16* __restrict__
 // whole scan (HPAD <= 128); otherwise (HPAD = 256: 512 KB of bf16 weights exceed one CU's register file) they are
 // re-streamed from L2 every step.  The time loop is straight-line code: lanes outside the batch / hidden range
 // compute on clamped addresses and simply do not store.
-template <int KS, int NT, bool WREG, int PF>
+// COOP (BT <= 2, i.e. batches of up to 512 sequences): the step inputs are fetched by the whole workgroup, one 16-byte
+// chunk per thread, PF steps ahead through a register ring and then a two-slot LDS ring.  With one or two live MFMA
+// columns a per-lane prefetch would park 16-32 VGPRs per step in flight in every lane for four useful lanes per wave,
+// which limits the depth to ~2 steps — less than the L2/MALL latency of the loads (measured: 1.6 of 2.1 us per step).
+template <int KS, int NT, bool WREG, int PF, bool COOP>
 __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restrict__ gx, const bf16* __restrict__ Wf,
                                      const float* __restrict__ h0, const float* __restrict__ c0,
                                      float* __restrict__ h_all, float* __restrict__ c_all, float* __restrict__ acts,
@@ -68,8 +72,23 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
     }
     for (int i = threadIdx.x; i < 2 * 16 * ldh; i += blockDim.x) hbuf[i] = (bf16)0.f;
     __syncthreads();
+    // COOP: "dense" gate math.  With nb <= 2 live MFMA columns only 4-8 lanes of a wave hold gate pre-activations, yet the
+    // ten transcendentals per hidden unit would issue for all 64 (2 x 640 quarter-rate cycles per SIMD and step — half of
+    // the step).  The accumulators are therefore re-dealt through a wave-private LDS patch so that lane (ds = lane>>4,
+    // du = lane&15) owns exactly one (sequence, hidden unit) pair; cell state, outputs and stores follow that layout.
+    __shared__ __attribute__((aligned(16))) float xch[COOP ? (NT / 64) * 256 : 4];      // per wave [gate][4 seq][16 units]
+    const int nb = (B - (int)blockIdx.x * BT) < BT ? (B - (int)blockIdx.x * BT) : BT;
+    const int ds = lane >> 4, du = lane & 15, ud = jt * 16 + du;
+    const int bd = blockIdx.x * BT + ds;
+    const bool lived = COOP && (ds < nb) && (ud < H);
+    float cd = 0.f;
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
-    if (live) {
+    if (COOP) {
+        if (lived) {
+            if (c0) cd = c0[(size_t)bd * H + ud];
+            if (h0) hbuf[ds * ldh + ud] = (bf16)h0[(size_t)bd * H + ud];
+        }
+    } else if (live) {
         if (c0) c = *reinterpret_cast<const f32x4*>(c0 + (size_t)b * H + j0);
         if (h0) {
             const f32x4 hv = *reinterpret_cast<const f32x4*>(h0 + (size_t)b * H + j0);
@@ -79,55 +98,117 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
     }
     __syncthreads();
 
-    const float* gxl = gx + (size_t)bc * 4 * H + jc;             // + t*B*4H + q*H
     const size_t gstep = (size_t)B * 4 * H;
     // input projections of the next PF steps are always in flight (register ring, statically indexed by unrolling)
-    f32x4 ring[PF][4];
+    constexpr int RW = COOP ? 1 : 4;
+    constexpr int SLOT = 2 * 4 * KP;                            // floats per LDS ring slot: [2 sequences][4H]
+    __shared__ __attribute__((aligned(16))) float gslot[COOP ? 2 * SLOT : 4];
+    f32x4 ring[PF][RW];
+    // per-lane form: this lane's 4 gate rows; cooperative form: chunk threadIdx.x of the workgroup's nb*4H floats
+    const bool ld_on = COOP ? ((int)threadIdx.x < nb * H) : true;
+    const int cb = ld_on ? (int)threadIdx.x / H : 0, co = ld_on ? 4 * ((int)threadIdx.x % H) : 0;
+    const float* gxl = COOP ? gx + ((size_t)(blockIdx.x * BT + cb) * 4 * H + co) : gx + (size_t)bc * 4 * H + jc;   // + t*gstep (+ q*H)
+    const int lds_dst = cb * 4 * H + co;
+    const int lds_src = (ds < nb ? ds : 0) * 4 * H + (ud < H ? ud : H - 1);      // dense lane's scalar of each gate
+    auto fetch = [&](f32x4 (&r)[RW], int t) {
+        const int tl = t < T ? t : T - 1;                       // clamped: the tail re-reads the last step (unused)
 #pragma unroll
-    for (int d = 0; d < PF; ++d) {
-        const int tl = d < T ? d : T - 1;
+        for (int q = 0; q < RW; ++q) r[q] = *reinterpret_cast<const f32x4*>(gxl + tl * gstep + (size_t)q * H);
+    };
+    if (COOP) {
+        f32x4 first[RW];
+        fetch(first, 0);
+        if (ld_on) *reinterpret_cast<f32x4*>(gslot + lds_dst) = first[0];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ring[d][q] = *reinterpret_cast<const f32x4*>(gxl + tl * gstep + (size_t)q * H);
+        for (int d = 0; d < PF; ++d) fetch(ring[d], d + 1);
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) fetch(ring[d], d);
     }
     int cur = 0;
-    auto step = [&](int t, f32x4 (&in)[4]) {
+    auto step = [&](int t, f32x4 (&in)[RW]) {
         f32x4 acc[4];
+        float gin[4];
+        if (COOP) {
+            const float* sl = gslot + (t & 1) * SLOT + lds_src;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = in[q];
-        {
-            const int tn = (t + PF < T) ? t + PF : T - 1;       // clamped: the tail re-reads the last step (unused)
+            for (int q = 0; q < 4; ++q) { gin[q] = sl[q * H]; acc[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            // hand step t+1's chunk to the other slot (its readers finished before the previous barrier), refill the ring
+            if (ld_on) *reinterpret_cast<f32x4*>(gslot + ((t + 1) & 1) * SLOT + lds_dst) = in[0];
+            fetch(in, t + 1 + PF);
+        } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) in[q] = *reinterpret_cast<const f32x4*>(gxl + tn * gstep + (size_t)q * H);
+            for (int q = 0; q < 4; ++q) acc[q] = in[q < RW ? q : 0];
+            fetch(in, t + PF);
         }
         const bf16* hb = hbuf + cur * 16 * ldh + l15 * ldh + 8 * lq;
+        if (WREG) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(hb + ks * 32);
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(hb + ks * 32);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bf16x8 af = WREG ? a[WREG ? q : 0][WREG ? ks : 0] : *reinterpret_cast<const bf16x8*>(wrow + q * wq + ks * 32);
-                acc[q] = mfma16(af, bf, acc[q]);
+                for (int q = 0; q < 4; ++q) acc[q] = mfma16(a[WREG ? q : 0][WREG ? ks : 0], bf, acc[q]);
+            }
+        } else {
+            // streamed weights: two k-blocks of fragments in flight; the scheduling fences keep hipcc from hoisting
+            // all 4*KS fragment loads to the top of the step (128 VGPRs at KS = 8: spills)
+            bf16x8 wa[2][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wa[0][q] = *reinterpret_cast<const bf16x8*>(wrow + q * wq);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) wa[(ks + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(wrow + q * wq + (ks + 1) * 32);
+                }
+                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(hb + ks * 32);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = mfma16(wa[ks & 1][q], bf, acc[q]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        f32x4 ig, fg, gg, og, hn;
+        if (COOP) {
+            float* xw = xch + jt * 256;
+            if (l15 < 4) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            ig[r] = sigmoid_f(acc[0][r]); fg[r] = sigmoid_f(acc[1][r]); gg[r] = tanh_f(acc[2][r]); og[r] = sigmoid_f(acc[3][r]);
-            c[r] = fg[r] * c[r] + ig[r] * gg[r];
-            hn[r] = live ? og[r] * tanh_f(c[r]) : 0.f;          // pad lanes keep h = 0 in LDS
-        }
-        bf16x4 hb4;
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(xw + (q * 4 + l15) * 16 + 4 * lq) = acc[q];
+            }
+            // same-wave LDS traffic is ordered: no barrier between the re-deal's writes and reads
+            const float ig = sigmoid_f(xw[(0 * 4 + ds) * 16 + du] + gin[0]), fg = sigmoid_f(xw[(1 * 4 + ds) * 16 + du] + gin[1]);
+            const float gg = tanh_f(xw[(2 * 4 + ds) * 16 + du] + gin[2]), og = sigmoid_f(xw[(3 * 4 + ds) * 16 + du] + gin[3]);
+            cd = fg * cd + ig * gg;
+            const float hn = lived ? og * tanh_f(cd) : 0.f;     // pad lanes keep h = 0 in LDS
+            hbuf[(cur ^ 1) * 16 * ldh + ds * ldh + ud] = (bf16)hn;
+            lds_barrier();                                      // h_t visible to every wave; global traffic stays in flight
+            if (lived) {
+                const size_t o = ((size_t)t * B + bd) * H + ud;
+                h_all[o] = hn;
+                c_all[o] = cd;
+                float* ap = acts + ((size_t)t * B + bd) * 4 * H + ud;
+                ap[0] = ig; ap[H] = fg; ap[2 * H] = gg; ap[3 * H] = og;
+            }
+        } else {
+            f32x4 ig, fg, gg, og, hn;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hb4[r] = (bf16)hn[r];
-        *reinterpret_cast<bf16x4*>(hbuf + (cur ^ 1) * 16 * ldh + l15 * ldh + jt * 16 + 4 * lq) = hb4;
-        lds_barrier();                                          // h_t visible to every wave; global traffic stays in flight
-        if (live) {
-            const size_t o = ((size_t)t * B + b) * H + j0;
-            *reinterpret_cast<f32x4*>(h_all + o) = hn;
-            *reinterpret_cast<f32x4*>(c_all + o) = c;
-            float* ap = acts + ((size_t)t * B + b) * 4 * H + j0;
-            *reinterpret_cast<f32x4*>(ap) = ig; *reinterpret_cast<f32x4*>(ap + H) = fg;
-            *reinterpret_cast<f32x4*>(ap + 2 * H) = gg; *reinterpret_cast<f32x4*>(ap + 3 * H) = og;
+            for (int r = 0; r < 4; ++r) {
+                ig[r] = sigmoid_f(acc[0][r]); fg[r] = sigmoid_f(acc[1][r]); gg[r] = tanh_f(acc[2][r]); og[r] = sigmoid_f(acc[3][r]);
+                c[r] = fg[r] * c[r] + ig[r] * gg[r];
+                hn[r] = live ? og[r] * tanh_f(c[r]) : 0.f;      // pad lanes keep h = 0 in LDS
+            }
+            bf16x4 hb4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hb4[r] = (bf16)hn[r];
+            *reinterpret_cast<bf16x4*>(hbuf + (cur ^ 1) * 16 * ldh + l15 * ldh + jt * 16 + 4 * lq) = hb4;
+            lds_barrier();                                      // h_t visible to every wave; global traffic stays in flight
+            if (live) {
+                const size_t o = ((size_t)t * B + b) * H + j0;
+                *reinterpret_cast<f32x4*>(h_all + o) = hn;
+                *reinterpret_cast<f32x4*>(c_all + o) = c;
+                float* ap = acts + ((size_t)t * B + b) * 4 * H + j0;
+                *reinterpret_cast<f32x4*>(ap) = ig; *reinterpret_cast<f32x4*>(ap + H) = fg;
+                *reinterpret_cast<f32x4*>(ap + 2 * H) = gg; *reinterpret_cast<f32x4*>(ap + 3 * H) = og;
+            }
         }
         cur ^= 1;
     };
@@ -142,7 +223,7 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
 
 // Backward through time.  dG[t] (gate pre-activation gradients, fp32 (T,B,4H)) is also what the batched
 // input-projection / weight gradients consume afterwards.  KS4 = 4*HPAD/32.
-template <int KS4, int NT, bool WREG, int PF>
+template <int KS4, int NT, bool WREG, int PF, bool COOP>
 __global__ __launch_bounds__(NT) void lstm_scan_bwd_kernel(const float* __restrict__ dh_ext, const float* __restrict__ dc_ext,
                                      const bf16* __restrict__ Wb, const float* __restrict__ c0,
                                      const float* __restrict__ c_all, const float* __restrict__ acts,
@@ -169,13 +250,16 @@ __global__ __launch_bounds__(NT) void lstm_scan_bwd_kernel(const float* __restri
     f32x4 dh_rec = {0.f, 0.f, 0.f, 0.f}, dc = {0.f, 0.f, 0.f, 0.f};
     // saved activations / cell states / external gradients of the next PF steps (going backwards) stay in flight
     struct StepIn { f32x4 ig, fg, gg, og, ct, cp, dhe, dce; };
-    StepIn ring[PF];
     const size_t ostep = (size_t)B * H;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int SLOT = 2 * 8 * HPAD;                          // floats per LDS ring slot: [2 sequences][8H]
+    float* gslot = reinterpret_cast<float*>(smem + (size_t)2 * 16 * ldg * sizeof(bf16));   // COOP only: [2][SLOT]
+    // ---- per-lane form
+    StepIn ring[COOP ? 1 : PF];
     const float* actl = acts + (size_t)bc * 4 * H + jc;
     const float* cl = c_all + (size_t)bc * H + jc;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 c0v = zero4;
-    if (c0) c0v = *reinterpret_cast<const f32x4*>(c0 + (size_t)bc * H + jc);
+    if (!COOP && c0) c0v = *reinterpret_cast<const f32x4*>(c0 + (size_t)bc * H + jc);
     auto fetch = [&](StepIn& r, int t) {
         const int tc = t > 0 ? t : 0;                           // clamped, branch-free
         const float* ap = actl + (size_t)tc * ostep * 4;
@@ -187,35 +271,100 @@ __global__ __launch_bounds__(NT) void lstm_scan_bwd_kernel(const float* __restri
         r.dhe = dh_ext ? *reinterpret_cast<const f32x4*>(dh_ext + (size_t)bc * H + jc + (size_t)tc * ostep) : zero4;
         r.dce = dc_ext ? *reinterpret_cast<const f32x4*>(dc_ext + (size_t)bc * H + jc + (size_t)tc * ostep) : zero4;
     };
+    // ---- cooperative form: thread i owns chunk i of the workgroup's nb*8H floats per step:
+    //      [sequence][ i f g o (acts, 4H) | c_t | c_{t-1} | dh_ext | dc_ext ]
+    const int nb = (B - (int)blockIdx.x * BT) < BT ? (B - (int)blockIdx.x * BT) : BT;
+    const bool ld_on = COOP && ((int)threadIdx.x < nb * 2 * H);
+    const int cb = ld_on ? (int)threadIdx.x / (2 * H) : 0, cof = ld_on ? 4 * ((int)threadIdx.x % (2 * H)) : 0;
+    const int seg = cof / H, so = cof - seg * H;                // H % 4 == 0: a chunk never straddles two segments
+    const size_t cbg = (size_t)(blockIdx.x * BT + cb);
+    const float* cbase = seg < 4 ? acts + cbg * 4 * H + cof
+                       : seg < 6 ? c_all + cbg * H + so
+                       : seg == 6 ? (dh_ext ? dh_ext + cbg * H + so : c_all) : (dc_ext ? dc_ext + cbg * H + so : c_all);
+    const size_t cstride = seg < 4 ? ostep * 4 : ostep;
+    const int cshift = seg == 5 ? 1 : 0;                        // c_{t-1}
+    const bool czero = (seg == 6 && !dh_ext) || (seg == 7 && !dc_ext);      // absent external gradient: zeros
+    f32x4 cfirst = zero4;                                       // c_{-1} = c0
+    if (COOP && ld_on && seg == 5 && c0) cfirst = *reinterpret_cast<const f32x4*>(c0 + cbg * H + so);
+    f32x4 cring[COOP ? PF : 1];
+    auto cfetch = [&](f32x4& r, int t) {
+        const int tt = (t > 0 ? t : 0) - cshift;
+        f32x4 v = *reinterpret_cast<const f32x4*>(cbase + (size_t)(tt > 0 ? tt : 0) * cstride);
+        if (tt < 0) v = cfirst;
+        r = czero ? zero4 : v;
+    };
+    const int lds_dst = cb * 8 * H + cof;
+    const int lds_src = (l15 < nb ? l15 : 0) * 8 * H + jc;
+    if (COOP) {
+        f32x4 first;
+        cfetch(first, T - 1);
+        if (ld_on) *reinterpret_cast<f32x4*>(gslot + lds_dst) = first;
 #pragma unroll
-    for (int d = 0; d < PF; ++d) fetch(ring[d], T - 1 - d);
+        for (int d = 0; d < PF; ++d) cfetch(cring[d], T - 2 - d);
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) fetch(ring[d], T - 1 - d);
+    }
     int cur = 0;
-    auto step = [&](int t, StepIn& slot) {
-        const StepIn in = slot;
-        fetch(slot, t - PF);
-        f32x4 dgi, dgf, dgg, dgo;
+    // dense gate math for the cooperative form (see the forward kernel): lane (ds, du) owns one (sequence, unit) pair
+    const int ds = lane >> 4, du = lane & 15, ud = jt * 16 + du;
+    const int bd = blockIdx.x * BT + ds;
+    const bool lived = COOP && (ds < nb) && (ud < H);
+    const float lvd = lived ? 1.f : 0.f;
+    const int dsrc = (ds < nb ? ds : 0) * 8 * H + (ud < H ? ud : H - 1);
+    float* xw = gslot + 2 * SLOT + jt * 64;                     // per-wave re-deal patch [4 seq][16 units]
+    float dhd = 0.f, dcd = 0.f;                                 // dense copies of dh_rec / dc
+    auto step = [&](int t, StepIn& slot, f32x4& cslot) {
+        if (COOP) {
+            const int it = T - 1 - t;                           // iteration counter: slot parity
+            const float* sl = gslot + (it & 1) * SLOT + dsrc;
+            const float ig = sl[0], fg = sl[H], gg = sl[2 * H], og = sl[3 * H], ct = sl[4 * H], cp = sl[5 * H];
+            const float dhe = sl[6 * H], dce = sl[7 * H];
+            if (ld_on) *reinterpret_cast<f32x4*>(gslot + ((it + 1) & 1) * SLOT + lds_dst) = cslot;    // step t-1's chunk
+            cfetch(cslot, t - 1 - PF);
+            const float dh = dhd + dhe;
+            const float th = tanh_f(ct);
+            const float dct = dcd + dce + dh * og * (1.f - th * th);
+            const float dgo = lvd * dh * th * og * (1.f - og);
+            const float dgi = lvd * dct * gg * ig * (1.f - ig);
+            const float dgf = lvd * dct * cp * fg * (1.f - fg);
+            const float dgg = lvd * dct * ig * (1.f - gg * gg);
+            dcd = dct * fg;
+            bf16* gw = gbuf + cur * 16 * ldg + ds * ldg + ud;
+            gw[0] = (bf16)dgi; gw[HPAD] = (bf16)dgf; gw[2 * HPAD] = (bf16)dgg; gw[3 * HPAD] = (bf16)dgo;
+            lds_barrier();
+            if (lived) {
+                float* gp = dG + ((size_t)t * B + bd) * 4 * H + ud;
+                gp[0] = dgi; gp[H] = dgf; gp[2 * H] = dgg; gp[3 * H] = dgo;
+            }
+        } else {
+            const StepIn in = slot;
+            fetch(slot, t - PF);
+            f32x4 dgi, dgf, dgg, dgo;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float dh = dh_rec[r] + in.dhe[r];
-            const float th = tanh_f(in.ct[r]);
-            const float dct = dc[r] + in.dce[r] + dh * in.og[r] * (1.f - th * th);
-            dgo[r] = lv * dh * th * in.og[r] * (1.f - in.og[r]);
-            dgi[r] = lv * dct * in.gg[r] * in.ig[r] * (1.f - in.ig[r]);
-            dgf[r] = lv * dct * in.cp[r] * in.fg[r] * (1.f - in.fg[r]);
-            dgg[r] = lv * dct * in.ig[r] * (1.f - in.gg[r] * in.gg[r]);
-            dc[r] = dct * in.fg[r];
-        }
-        bf16* gw = gbuf + cur * 16 * ldg + l15 * ldg + jt * 16 + 4 * lq;
-        bf16x4 p0, p1, p2, p3;
+            for (int r = 0; r < 4; ++r) {
+                const float dh = dh_rec[r] + in.dhe[r];
+                const float th = tanh_f(in.ct[r]);
+                const float dct = dc[r] + in.dce[r] + dh * in.og[r] * (1.f - th * th);
+                dgo[r] = lv * dh * th * in.og[r] * (1.f - in.og[r]);
+                dgi[r] = lv * dct * in.gg[r] * in.ig[r] * (1.f - in.ig[r]);
+                dgf[r] = lv * dct * in.cp[r] * in.fg[r] * (1.f - in.fg[r]);
+                dgg[r] = lv * dct * in.ig[r] * (1.f - in.gg[r] * in.gg[r]);
+                dc[r] = dct * in.fg[r];
+            }
+            bf16* gw = gbuf + cur * 16 * ldg + l15 * ldg + jt * 16 + 4 * lq;
+            bf16x4 p0, p1, p2, p3;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { p0[r] = (bf16)dgi[r]; p1[r] = (bf16)dgf[r]; p2[r] = (bf16)dgg[r]; p3[r] = (bf16)dgo[r]; }
-        *reinterpret_cast<bf16x4*>(gw) = p0; *reinterpret_cast<bf16x4*>(gw + HPAD) = p1;
-        *reinterpret_cast<bf16x4*>(gw + 2 * HPAD) = p2; *reinterpret_cast<bf16x4*>(gw + 3 * HPAD) = p3;
-        lds_barrier();
-        if (live) {
-            float* gp = dG + ((size_t)t * B + b) * 4 * H + j0;
-            *reinterpret_cast<f32x4*>(gp) = dgi; *reinterpret_cast<f32x4*>(gp + H) = dgf;
-            *reinterpret_cast<f32x4*>(gp + 2 * H) = dgg; *reinterpret_cast<f32x4*>(gp + 3 * H) = dgo;
+            for (int r = 0; r < 4; ++r) { p0[r] = (bf16)dgi[r]; p1[r] = (bf16)dgf[r]; p2[r] = (bf16)dgg[r]; p3[r] = (bf16)dgo[r]; }
+            *reinterpret_cast<bf16x4*>(gw) = p0; *reinterpret_cast<bf16x4*>(gw + HPAD) = p1;
+            *reinterpret_cast<bf16x4*>(gw + 2 * HPAD) = p2; *reinterpret_cast<bf16x4*>(gw + 3 * HPAD) = p3;
+            lds_barrier();
+            if (live) {
+                float* gp = dG + ((size_t)t * B + b) * 4 * H + j0;
+                *reinterpret_cast<f32x4*>(gp) = dgi; *reinterpret_cast<f32x4*>(gp + H) = dgf;
+                *reinterpret_cast<f32x4*>(gp + 2 * H) = dgg; *reinterpret_cast<f32x4*>(gp + 3 * H) = dgo;
+            }
         }
         const bf16* gb = gbuf + cur * 16 * ldg + l15 * ldg + 8 * lq;
         // four independent accumulation chains (one per gate block of the contraction): a single chain of KS4
@@ -224,27 +373,41 @@ __global__ __launch_bounds__(NT) void lstm_scan_bwd_kernel(const float* __restri
         // the B operand (all 4H gate gradients of a sequence) is the LDS-bandwidth term of a step: 16 KB per wave
         // at H = 128.  Only the BT live MFMA columns are read; the other lanes keep whatever their registers
         // held (a column of D depends on the same column of B only, and dead columns are never stored).
-        bf16x8 bfr[KS4];
-        if (l15 < BT) {
+        constexpr int KG = WREG ? KS4 : 8;                      // B fragments fetched per group (register budget)
 #pragma unroll
-            for (int ks = 0; ks < KS4; ++ks) bfr[ks] = *reinterpret_cast<const bf16x8*>(gb + ks * 32);
-        }
+        for (int k0 = 0; k0 < KS4; k0 += KG) {
+            bf16x8 bfr[KG];
+            if (l15 < BT) {
 #pragma unroll
-        for (int ks = 0; ks < KS4; ++ks) {
-            const bf16x8 af = WREG ? a[WREG ? ks : 0] : *reinterpret_cast<const bf16x8*>(wrow + ks * 32);
-            acc[ks & 3] = mfma16(af, bfr[ks], acc[ks & 3]);
+                for (int ks = 0; ks < KG; ++ks) bfr[ks] = *reinterpret_cast<const bf16x8*>(gb + (k0 + ks) * 32);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KG; ++ks) {
+                const bf16x8 af = WREG ? a[WREG ? k0 + ks : 0] : *reinterpret_cast<const bf16x8*>(wrow + (k0 + ks) * 32);
+                acc[ks & 3] = mfma16(af, bfr[ks], acc[ks & 3]);
+            }
+            if (!WREG) __builtin_amdgcn_sched_barrier(0);       // keep the next group's fragment loads below this point
         }
         dh_rec = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        if (COOP) {                                             // re-deal dh_rec to the dense lanes (same-wave LDS: ordered)
+            if (l15 < 4) *reinterpret_cast<f32x4*>(xw + l15 * 16 + 4 * lq) = dh_rec;
+            dhd = xw[ds * 16 + du];
+        }
         cur ^= 1;
     };
     int tb = T - 1;
     for (; tb - PF + 1 >= 0; tb -= PF) {
 #pragma unroll
-        for (int d = 0; d < PF; ++d) step(tb - d, ring[d]);
+        for (int d = 0; d < PF; ++d) step(tb - d, ring[COOP ? 0 : d], cring[COOP ? d : 0]);
     }
 #pragma unroll
-    for (int d = 0; d < PF; ++d) if (tb - d >= 0) step(tb - d, ring[d]);
-    if (live) {
+    for (int d = 0; d < PF; ++d) if (tb - d >= 0) step(tb - d, ring[COOP ? 0 : d], cring[COOP ? d : 0]);
+    if (COOP) {
+        if (lived) {
+            if (dh0) dh0[(size_t)bd * H + ud] = dhd;
+            if (dc0) dc0[(size_t)bd * H + ud] = dcd;
+        }
+    } else if (live) {
         if (dh0) *reinterpret_cast<f32x4*>(dh0 + (size_t)b * H + j0) = dh_rec;
         if (dc0) *reinterpret_cast<f32x4*>(dc0 + (size_t)b * H + j0) = dc;
     }

@@ -39,7 +39,9 @@ def _oracle_lstm(gx, W, h0, c0):
 
 
 @pytest.mark.parametrize("T,B,H,init", [(20, 3, 88, False), (7, 17, 48, False), (50, 4, 128, True), (12, 33, 40, True),
-                                        (1, 1, 16, False), (9, 5, 256, True)])
+                                        (1, 1, 16, False), (9, 5, 256, True),
+                                        # > 256 sequences: 2 per workgroup; > 512: 4+ per workgroup and the per-lane loader
+                                        (6, 300, 88, True), (5, 601, 48, True), (4, 1100, 128, False)])
 def test_lstm_scan(dev, T, B, H, init):
     tag = "lstm%d_%d_%d" % (T, B, H)
     gx = R.gen_normal(tag + "gx", (T, B, 4 * H), 13)
@@ -75,7 +77,7 @@ def _oracle_mem_scan(apre, chat, Wm, W2, b2):
     return torch.stack(out)
 
 
-@pytest.mark.parametrize("T,B", [(20, 3), (1, 1), (33, 18)])
+@pytest.mark.parametrize("T,B", [(20, 3), (1, 1), (33, 18), (5, 300), (3, 1030)])
 def test_mfn_mem_scan(dev, T, B):
     tag = "mem%d_%d" % (T, B)
     apre = R.gen_normal(tag + "a", (T, B, 128), 17)
