@@ -233,10 +233,10 @@ static DropCfg no_drop() { return make_drop(0.f, 0, 0); }
 
 static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* VT, bf16* ctx, bf16* ctxT, float* lse,
                            const EncDims& D, hipStream_t st, DropCfg drop = no_drop()) {
-    dim3 grid((D.nt + 3) / 4, D.B * D.h);
+    dim3 grid(attn_grid((D.nt + 3) / 4, D.B * D.h));
     ProfScope prof(S_ATTN_FWD, st);
 #define MMT_FWD(dkp, dr) hipLaunchKernelGGL((attn_fwd_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, \
-                                            D.h, D.T, D.nt, D.L.HDP, D.MP, drop)
+                                            D.h, D.T, D.nt, D.B * D.h, D.L.HDP, D.MP, drop)
     if (DKP == 16) { if (drop.thr16) MMT_FWD(16, true); else MMT_FWD(16, false); }
     else { if (drop.thr16) MMT_FWD(32, true); else MMT_FWD(32, false); }
 #undef MMT_FWD
@@ -248,12 +248,12 @@ static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* 
 static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* KR, const bf16* KT_, const bf16* VR,
                            const bf16* dOR, const bf16* dOT, const float* lse, const float* delta, const float* rowmask,
                            bf16* dqkv, bf16* dqkvT, const EncDims& D, hipStream_t st, DropCfg drop = no_drop()) {
-    dim3 grid((D.nt + 3) / 4, D.B * D.h);
+    dim3 grid(attn_grid((D.nt + 3) / 4, D.B * D.h));
     const float scale = 1.0f / sqrtf((float)D.L.dk);
     {
         ProfScope prof(S_ATTN_BWD, st);
 #define MMT_DKV(dkp, dr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, QT, KR, VR, dOR, dOT, lse, delta, \
-                                            dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, drop)
+                                            dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, D.B * D.h, drop)
         if (DKP == 16) { if (drop.thr16) MMT_DKV(16, true); else MMT_DKV(16, false); }
         else { if (drop.thr16) MMT_DKV(32, true); else MMT_DKV(32, false); }
 #undef MMT_DKV
@@ -262,7 +262,7 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
     {
         ProfScope prof(S_DQ_FINISH, st);
 #define MMT_DQ(dkp, dr) hipLaunchKernelGGL((attn_bwd_dq_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, KT_, VR, dOR, lse, delta, rowmask, \
-                                           scale, dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, drop)
+                                           scale, dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, D.B * D.h, drop)
         if (DKP == 16) { if (drop.thr16) MMT_DQ(16, true); else MMT_DQ(16, false); }
         else { if (drop.thr16) MMT_DQ(32, true); else MMT_DQ(32, false); }
 #undef MMT_DQ

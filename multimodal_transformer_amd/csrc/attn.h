@@ -68,21 +68,39 @@ __device__ __forceinline__ void drop_probs_qlane(f32x16& v, const DropCfg& dc, u
 // (row 16 of V^T is synthesised as ones) unless dropout is on (the normaliser uses the undropped P).
 #define MMT_RESCALE_THR 8.0f
 
+// Workgroup -> (tile quad bx, batch*head bh).  The (nt+3)/4 workgroups that sweep the same (batch, head) all stream
+// that head's whole K/V (forward) or Q/dO (backward) fragments.  The hardware deals consecutive workgroup ids round-robin
+// to the 8 XCDs, each with a private L2, so a plain 2-D grid would put the sharers on different XCDs and fetch the
+// operands once per sharer from the fabric (measured with FETCH_SIZE: 2.5-3x the operand bytes).  A 1-D grid of
+// nx * 8 * ceil(nbh/8) ids is decoded so that ids congruent mod 8 — same XCD — carry the same head.
+struct AttnBlock { int bx, bh; bool valid; };
+__device__ __forceinline__ AttnBlock attn_block(int nx, int nbh) {
+    const int L = blockIdx.x, grp = L / (8 * nx), rem = L - grp * 8 * nx;
+    AttnBlock a;
+    a.bx = rem >> 3;
+    a.bh = grp * 8 + (rem & 7);
+    a.valid = a.bh < nbh;
+    return a;
+}
+__host__ inline int attn_grid(int nx, int nbh) { return nx * 8 * ((nbh + 7) / 8); }
+
 template <int DKP, bool DROP>
 __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
         const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vt,
         bf16* __restrict__ ctx, bf16* __restrict__ ctxT, float* __restrict__ lse,
-        int h, int T, int nt, int ldc, int MP, DropCfg drop) {
+        int h, int T, int nt, int nbh, int ldc, int MP, DropCfg drop) {
     constexpr int KS = DKP / 16;
     constexpr bool ONES = (DKP == 16) && !DROP;        // row sums through the MFMA
     constexpr int PK = DKP * 4, PV = 128;              // 16-byte pieces of one K (R layout) / V (T layout) tile
     __shared__ __attribute__((aligned(16))) bf16 stage[2][(PK + PV) * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int qt = blockIdx.x * 4 + wave;
+    const AttnBlock ab = attn_block((nt + 3) >> 2, nbh);
+    if (!ab.valid) return;                              // whole workgroup, before any barrier
+    const int qt = ab.bx * 4 + wave;
     const bool live = qt < nt;                          // idle waves still stage and synchronise
     const int qtc = live ? qt : nt - 1;
-    const int bh = blockIdx.y, b = bh / h, head = bh - b * h;
+    const int bh = ab.bh, b = bh / h, head = bh - b * h;
     const int Tp = nt * 32;
     const bf16* Qb = Qr + (size_t)bh * fragR_elems(Tp, DKP);
     const bf16* Kb = Kr + (size_t)bh * fragR_elems(Tp, DKP);
@@ -197,17 +215,19 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dkv_kernel(
         const float* __restrict__ lse, const float* __restrict__ delta,
         bf16* __restrict__ dkv, int lddkv,      // row-major [M][lddkv]; dK at column HD, dV at 2*HD
         bf16* __restrict__ dkvT, int MP,        // T layout  [3*HD rows][MP]
-        int h, int T, int nt, DropCfg drop) {
+        int h, int T, int nt, int nbh, DropCfg drop) {
     constexpr int KS = DKP / 16;
     constexpr int PR = DKP * 4, PT = 128, PC = 8;       // pieces: R-layout tile, T-layout tile, 32 fp32 row constants
     constexpr int TOTAL = 2 * PR + 2 * PT + 2 * PC;
     __shared__ __attribute__((aligned(16))) bf16 stage[2][TOTAL * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int kt = blockIdx.x * 4 + wave;
+    const AttnBlock ab = attn_block((nt + 3) >> 2, nbh);
+    if (!ab.valid) return;                              // whole workgroup, before any barrier
+    const int kt = ab.bx * 4 + wave;
     const bool live = kt < nt;
     const int ktc = live ? kt : nt - 1;
-    const int bh = blockIdx.y, b = bh / h, head = bh - b * h;
+    const int bh = ab.bh, b = bh / h, head = bh - b * h;
     const int Tp = nt * 32, HD = h * DKP;
     const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
     const bf16 *Krb = Kr + offR, *Vrb = Vr + offR;
@@ -339,16 +359,18 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
         const bf16* __restrict__ dOr, const float* __restrict__ lse, const float* __restrict__ delta,
         const float* __restrict__ rowmask, float scale,
         bf16* __restrict__ dqkv, int lddqkv, bf16* __restrict__ dqkvT, int MP,
-        int h, int T, int nt, DropCfg drop) {
+        int h, int T, int nt, int nbh, DropCfg drop) {
     constexpr int KS = DKP / 16;
     constexpr int PR = DKP * 4, PT = 128;
     __shared__ __attribute__((aligned(16))) bf16 stage[2][(2 * PR + PT) * 8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int qt = blockIdx.x * 4 + wave;
+    const AttnBlock ab = attn_block((nt + 3) >> 2, nbh);
+    if (!ab.valid) return;                              // whole workgroup, before any barrier
+    const int qt = ab.bx * 4 + wave;
     const bool live = qt < nt;
     const int qtc = live ? qt : nt - 1;
-    const int bh = blockIdx.y, b = bh / h, head = bh - b * h;
+    const int bh = ab.bh, b = bh / h, head = bh - b * h;
     const int Tp = nt * 32;
     const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
     const bf16 *Qrb = Qr + offR, *dOrb = dOr + offR;
