@@ -66,6 +66,37 @@ def site_flops_per_launch(site, M, T, d, f, n_layers=1):
     return table.get(site, 0) * M
 
 
+SITE_KERNELS = {          # launch site -> kernel symbol prefix in the rocprofv3 tables
+    "attn_fwd_kernel": "attn_fwd_kernel", "attn_bwd_dkv_kernel": "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel": "attn_bwd_dq_kernel",
+    "chain:outproj+res>ln2+ffn1>ffn2+res": "encoder_post_attn_fwd_kernel",
+    "chain:bwd_ffn2>bwd_ffn1+ln2>bwd_outproj->dO": "encoder_pre_attn_bwd_kernel",
+    "rowgemm<FRAG,LN>:ln1+qkv": "rowgemm_kernel<1, true>", "rowgemm<LNBWD>:bwd_qkv+ln1": "rowgemm_kernel<2, false>",
+    "wgrad_kernel": "wgrad_kernel",
+}
+
+
+def pmc_traffic(site, train, cfg):
+    """HBM-side bytes per launch of the site's kernel from the committed rocprofv3 counter summary (separate --pmc passes of
+    this same workload; FETCH_SIZE x2 + WRITE_SIZE, KiB units — MI355X_MICROARCH.md 'HBM').  bench.py cannot run the
+    profiler around itself, so the figure is read from profiles/; None if the workload differs or the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_per_kernel.json")
+    if not os.path.exists(path) or site not in SITE_KERNELS:
+        return None, None
+    try:
+        with open(path) as fh:
+            tab = json.load(fh)
+    except (OSError, ValueError):
+        return None, None
+    meta = tab.get("_meta", {})
+    if meta.get("workload") != cfg["desc"] or bool(meta.get("train")) != bool(train):
+        return None, None
+    pref = SITE_KERNELS[site]
+    for k, v in tab.items():
+        if k.startswith(pref) and "hbm_bytes_per_launch" in v:
+            return int(v["hbm_bytes_per_launch"]), "profiles/r01_pmc_per_kernel.json (%s)" % k
+    return None, None
+
+
 def make_encoder(cfg):
     from multimodal_transformer_amd import multiTransformer as MT
     torch.manual_seed(1)                                    # transformer/SFT/train.py:522
@@ -239,8 +270,9 @@ def main():
         avg_s = tot_ms / cnt * 1e-3
         fl = site_flops_per_launch(name, M, T, d, f, N)
         ach = fl / avg_s / 1e12 if avg_s > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(name, train, cfg)
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": None,
+                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": cnt // args.profile_steps,
                     "flops_per_launch": fl,
                     "share_of_kernel_time": round(tot_ms / sum(v[0] for v in prof.values()), 3)}
@@ -276,6 +308,34 @@ def main():
                 "value": round(M * nst / el, 1), "unit": "windows/s", "ms_per_step": round(1e3 * el / nst, 4), "launch": mrun.launch,
                 "kernel_ms_per_step": {k: round(v[0] / 3, 4) for k, v in sorted(mp_.items(), key=lambda kv: -kv[1][0])[:8]}}
 
+    # ---- whole MFT model at configs[2] (3 modalities, T=300, 32 sequences), N=1 only
+    mft = None
+    if rank == 0 and world == 1 and not args.no_full_model and args.workload == "C4":
+        from multimodal_transformer_amd import multiTransformer as MT
+        torch.manual_seed(1)
+        mods = ["acoustic", "image", "linguistic"]                       # transformer/MFT/train.py default modality set order
+        dims = {"acoustic": 88, "image": 256, "linguistic": 300}
+        Bm, Tm = 32, 300
+        mmodel = MT.MultiTransformer(mods, dims, device=dev)
+        mmodel.train(train)
+        mparams2 = list(mmodel.parameters())
+        xin2 = {m: torch.randn(Bm, Tm, dims[m], generator=g).to(dev) for m in mods}
+        mask2 = torch.ones(Bm, Tm, 1, device=dev)
+        tgt2 = torch.rand(Bm, Tm, 1, generator=g).to(dev)
+
+        def mft_step():
+            for p in mparams2:
+                p.grad = None
+            loss = ((mmodel(xin2, mask2, [Tm] * Bm) - tgt2) ** 2).sum() / float(Bm * Tm)
+            loss.backward()
+
+        mrun2 = Runner(mft_step, mparams2, 1, not args.no_graph, 3)
+        nst2 = max(5, args.steps // 2)
+        el2 = mrun2.timed(nst2)
+        mft = {"model": "MultiTransformer(acoustic 88, image 256, linguistic 300 -> 256): 3 embeds + 3 encoder stacks (d=256, h=8, N=6) "
+                        "on concurrent streams + MFN gate; T=300, 32 sequences (configs[2])",
+               "value": round(Bm * Tm * nst2 / el2, 1), "unit": "windows/s", "ms_per_step": round(1e3 * el2 / nst2, 4), "launch": mrun2.launch}
+
     if rank == 0:
         fpw = 3 * N * flops_per_window_layer_fwd(d, T, f)
         out = {
@@ -297,6 +357,8 @@ def main():
         }
         if full is not None:
             out["full_model"] = full
+        if mft is not None:
+            out["mft_model"] = mft
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))

@@ -97,30 +97,40 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+SIDE_LANES = {}       # raw stream handle -> lane id (>= 1); filled by multiTransformer._ModalityStreams
+
+
 class WorkspacePool:
-    """Zero-initialised device workspaces, reused per (device, size).
+    """Zero-initialised device workspaces, reused per (device, stream lane, size).
 
     The kernels rely on pad regions of a workspace staying zero; they never write them, so a buffer
     can be reused for the same shape without clearing.  A buffer is held by the autograd node between
-    forward and backward and handed back afterwards.
+    forward and backward and handed back afterwards.  Lanes: the side streams on which the per-modality
+    encoders of the MFT run concurrently are registered in SIDE_LANES and each owns its buffers; every
+    other stream (the caller's, a hipGraph capture stream) is lane 0 with the usual in-order semantics.
+    So concurrent streams are never handed a workspace another stream's kernels may still be using, and a
+    graph capture after warm-up finds its buffers in the pool instead of allocating (and re-zeroing) them.
     """
 
     def __init__(self):
         self._free = {}
+        self._home = {}
 
     def get(self, nbytes, device):
-        key = (str(device), int(nbytes))
+        key = (str(device), SIDE_LANES.get(int(torch.cuda.current_stream(device).cuda_stream), 0), int(nbytes))
         lst = self._free.get(key)
-        if lst:
-            return lst.pop()
-        return torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        buf = lst.pop() if lst else torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        self._home[buf.data_ptr()] = key
+        return buf
 
     def put(self, buf):
-        key = (str(buf.device), buf.numel())
-        self._free.setdefault(key, []).append(buf)
+        key = self._home.get(buf.data_ptr())
+        if key is not None:
+            self._free.setdefault(key, []).append(buf)
 
     def clear(self):
         self._free.clear()
+        self._home.clear()
 
 
 POOL = WorkspacePool()

@@ -13,10 +13,12 @@ Deviations, all documented in DESIGN.md:
     global generator: training-mode parity with the reference is statistical, eval-mode is numerical.
 """
 import copy
+import os
 
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import functional as F_hip
 
 
@@ -199,6 +201,41 @@ def _encoder(embed_dim, h, d_ff, dropout, N):
                                 dropout), N)
 
 
+class _ModalityStreams:
+    """The modalities of the MFT are independent until the MFN gate: their embeds, encoder stacks and LSTM scans
+    run on one HIP stream each (the first on the caller's stream).  One stack at the reference sizes fills only part
+    of the 256 CUs (B*T/32 workgroups of four waves), so concurrency, not a faster kernel, is what is missing.
+    Fork/join is by event (``wait_stream``), which is also legal inside hipGraph capture; autograd replays each
+    backward node on the stream of its forward.  ``MMT_MODALITY_STREAMS=0`` serialises everything on one stream."""
+
+    def __init__(self):
+        self._side = {}
+
+    def begin(self, device, n):
+        main = torch.cuda.current_stream(device)
+        if os.environ.get("MMT_MODALITY_STREAMS", "1") == "0" or n < 2:
+            return main, [main] * n
+        side = self._side.setdefault(str(device), [])
+        while len(side) < n - 1:
+            side.append(torch.cuda.Stream(device=device))
+            _lib.SIDE_LANES[int(side[-1].cuda_stream)] = len(_lib.SIDE_LANES) + 1       # own workspace lane (see WorkspacePool)
+        streams = [main] + side[:n - 1]
+        for s in streams[1:]:
+            s.wait_stream(main)
+        return main, streams
+
+    @staticmethod
+    def end(main, streams, tensors):
+        for s in set(streams):
+            if s is not main:
+                main.wait_stream(s)
+        for t in tensors:
+            t.record_stream(main)
+
+
+_MOD_STREAMS = _ModalityStreams()
+
+
 class MFN(nn.Module):
     """Memory Fusion Network gate (transformer/MFT/multiTransformer.py:118-248).
 
@@ -250,14 +287,17 @@ class MFN(nn.Module):
         self._seed_counter = getattr(self, "_seed_counter", 0) + 1
         seed = (torch.initial_seed() * 1000003 + 7919 * self._seed_counter) & 0x7FFFFFFFFFFFFFFF
         hs, c_prev, c_new = [], [], []
-        for mod in self.mods:
-            cell = self.lstm[mod]
-            x = inputs[mod]                                           # (T,B,d), possibly a permuted view
-            gx = F_hip.linear(x, cell.weight_ih, cell.bias_ih + cell.bias_hh)
-            h_all, c_all = F_hip.lstm_scan(gx, cell.weight_hh)
-            hs.append(h_all)
-            c_new.append(c_all)
-            c_prev.append(torch.cat([torch.zeros_like(c_all[:1]), c_all[:-1]], dim=0))
+        main, streams = _MOD_STREAMS.begin(self.device, len(self.mods))
+        for mod, st in zip(self.mods, streams):
+            with torch.cuda.stream(st):
+                cell = self.lstm[mod]
+                x = inputs[mod]                                       # (T,B,d), possibly a permuted view
+                gx = F_hip.linear(x, cell.weight_ih, cell.bias_ih + cell.bias_hh)
+                h_all, c_all = F_hip.lstm_scan(gx, cell.weight_hh)
+                hs.append(h_all)
+                c_new.append(c_all)
+                c_prev.append(torch.cat([torch.zeros_like(c_all[:1]), c_all[:-1]], dim=0))
+        _MOD_STREAMS.end(main, streams, hs + c_new + c_prev)
         c_star = torch.cat(c_prev + c_new, dim=-1)                    # (T,B,2*sumH)   :215-217
         A = c_star.shape[-1]
         att = torch.softmax(F_hip.linear(F_hip.linear(c_star, self.att1_fc1.weight, self.att1_fc1.bias, act=1),
@@ -305,10 +345,13 @@ class MultiTransformer(nn.Module):
 
     def forward(self, inputs, mask, lengths, tgt_init=0.5, target=None):
         gate_in = {}
-        for mod in self.mods:
-            e = F_hip.linear(inputs[mod], self.embed[mod].weight, self.embed[mod].bias)
-            e = self.transformer[mod](e, mask)
-            gate_in[mod] = e.permute(1, 0, 2)
+        main, streams = _MOD_STREAMS.begin(self.device, len(self.mods))
+        for mod, st in zip(self.mods, streams):
+            with torch.cuda.stream(st):
+                e = F_hip.linear(inputs[mod], self.embed[mod].weight, self.embed[mod].bias)
+                e = self.transformer[mod](e, mask)
+                gate_in[mod] = e.permute(1, 0, 2)
+        _MOD_STREAMS.end(main, streams, list(gate_in.values()))
         return self.mfn(gate_in) * mask.float()
 
 

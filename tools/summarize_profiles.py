@@ -49,8 +49,23 @@ for k, cs in pmc.items():
         res[k]["hbm_read_bytes_per_launch"] = 2.0 * 1024.0 * res[k].get("FETCH_SIZE", 0.0)
         res[k]["hbm_write_bytes_per_launch"] = 1024.0 * res[k].get("WRITE_SIZE", 0.0)
         res[k]["hbm_bytes_per_launch"] = res[k]["hbm_read_bytes_per_launch"] + res[k]["hbm_write_bytes_per_launch"]
+# which workload the counters belong to (bench.py checks this before quoting a traffic figure)
+for f in glob.glob(os.path.join(out, "pmc_FETCH_SIZE.json")):
+    try:
+        line = [l for l in open(f) if l.startswith("{")][-1]
+        cfg = json.loads(line)["config"]
+        res["_meta"] = {"workload": cfg["workload"].split("; fwd")[0], "train": cfg["dropout"].startswith("train"),
+                        "command": "rocprofv3 --kernel-trace --pmc <one counter group per run> -- python3 bench.py --steps 3 --warmup 1 "
+                                   "--profile-steps 0 --no-graph --no-full-model --no-cpu-baseline",
+                        "units": "averages per dispatch; FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_* bytes = 2*1024*FETCH_SIZE + "
+                                 "1024*WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md 'HBM'); SQ_* cycle counters in quad-cycles "
+                                 "except SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CYCLES"}
+    except (IndexError, KeyError, ValueError) as e:
+        print("no _meta:", e)
 json.dump(res, open(os.path.join(out, "summary", "pmc_per_kernel.json"), "w"), indent=1, sort_keys=True)
 print("pmc_per_kernel.json: %d kernels" % len(res))
-for k in sorted(res, key=lambda k: -res[k].get("SQ_BUSY_CYCLES", res[k].get("hbm_bytes_per_launch", 0))):
+for k in sorted((k for k in res if k != "_meta"), key=lambda k: -res[k].get("SQ_BUSY_CYCLES", res[k].get("hbm_bytes_per_launch", 0))):
     r = res[k]
+    if k.startswith("at::") or k.startswith("__amd"):
+        continue
     print("%-44s n=%-4d" % (k[:44], r["dispatches"]), " ".join("%s=%.4g" % (c, v) for c, v in sorted(r.items()) if c != "dispatches"))
