@@ -134,7 +134,16 @@ def cpu_baseline(cfg, seconds_budget=15.0):
         if time.perf_counter() - t0 > seconds_budget or n >= 10:
             break
     dt = (time.perf_counter() - t0) / n
-    return {"value": round(Bs * T / dt, 1), "unit": "windows/s", "cores": cores, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(Bs * T / dt, 1), "unit": "windows/s", "cores": cores, "cpu": cpu_model, "kind": "port",
             "sample": "%d steps of the CPU oracle (fp32 torch-CPU port of the reference path, dropout as identity) on %d of the %d "
                       "sequences, same T/d/h/N; %.3f s/step" % (n, Bs, cfg["B"], dt)}
 
@@ -256,6 +265,26 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * M * args.steps / elapsed
 
+    # ---- the same step followed by the reference's optimiser (Adam lr 1e-4, weight decay 1e-4: transformer/SFT/train.py:621);
+    #      reported beside the headline, never as it ("with and without Adam + all-reduce")
+    adam = None
+    if rank == 0 or world > 1:
+        opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-4, foreach=True)
+        def step_adam():
+            run.step()
+            opt.step()
+        for _ in range(2):
+            step_adam()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_adam()
+        torch.cuda.synchronize()
+        adam = {"ms_per_step": round(1e3 * (time.perf_counter() - t0) / args.steps, 4),
+                "what": "step + torch.optim.Adam(foreach) on the %d parameter tensors%s" % (len(params), " + gradient all-reduce" if world > 1 else "")}
+
     # ---- per-kernel timing (HIP events on the launch stream), eager, outside the timed region
     roofline, kernel_ms = None, {}
     if rank == 0 and args.profile_steps > 0:
@@ -355,6 +384,8 @@ def main():
             "roofline": roofline,
             "kernel_ms_per_step": kernel_ms,
         }
+        if adam is not None:
+            out["with_adam"] = adam
         if full is not None:
             out["full_model"] = full
         if mft is not None:
