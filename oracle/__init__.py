@@ -22,3 +22,6 @@ from .models_ref import (  # noqa: F401
     multi_transformer, nlp_transformer, uni_full_transformer, lstm_decoder_head,
 )
 from .metrics import eval_ccc, masked_mse_sum_loss  # noqa: F401
+from .frontend_ref import (  # noqa: F401
+    cnn_maxpool, highway, window_encoder, multi_cnn_transformer_sft, multi_cnn_transformer_mft, multi_cnn_transformer_b2,
+)

@@ -88,3 +88,17 @@ SEED = 1
 
 def to_np(t):
     return t.detach().cpu().numpy().astype(np.float32)
+
+
+# ---- window-encoder front-end cases (make_golden_frontend.py) ------------------------------------------
+# (name, raw feature size D, window embed size F, positions per window W, windows N)
+CNN_CASES = [
+    ("fe_cnn_small", 40, 64, 7, 10),
+    ("fe_cnn_audio", 88, 256, 10, 6),         # transformer/SFT/train.py:534 dims, models.py:90 embed sizes
+    ("fe_cnn_text", 300, 300, 33, 4),
+    ("fe_cnn_image", 1000, 256, 30, 3),
+    ("fe_cnn_tall", 24, 32, 70, 3),           # more than 32 conv positions per window
+]
+FE_DIMS = {"linguistic": 300, "emotient": 20, "acoustic": 88, "image": 1000}
+FE_WINDOW = {"linguistic": 33, "emotient": 9, "acoustic": 10, "image": 30}
+FE_EMBED_MFT = {"linguistic": 300, "emotient": 20, "acoustic": 88, "image": 256}     # transformer/MFT/train.py:552 (A_dim = 88)
