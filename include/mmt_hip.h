@@ -138,6 +138,21 @@ int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* chat, const fl
                               float* dchat, float* dapre, float* dz_all, void* workspace, size_t workspace_bytes,
                               int T, int B, int mem_dim, int h_gamma, float dropout_p, mmt_stream_t stream);
 
+/* ---- Window encoder: Conv1d(D -> F, kernel 2, bias) over the W positions (tokens / frames) of each window followed by
+ *      the global max-pool over the W-1 conv positions.  Replaces CNN.forward
+ *                                                             transformer/SFT/models.py:57-79 (call site :118-127;
+ *                                                             same class in MFT/models.py:57-79, B2-Trans/models.py:57-79)
+ * x fp32 (N, W, D) contiguous: N = B*T windows (the reference loops over the batch; windows are independent), D % 4 == 0,
+ * W >= 2.  weight fp32 (F, D, 2) in nn.Conv1d's layout, bias (F).  out fp32 (N, F); argmax int32 (N, F): the conv position
+ * of the maximum (first one on ties), saved for the backward.  Only kernel size 2 (the reference's constant, :82). */
+size_t mmt_convpool_workspace_bytes(int N, int W, int D, int F);
+int mmt_convpool_forward(const float* x, const float* weight, const float* bias, float* out, int32_t* argmax,
+                         void* workspace, size_t workspace_bytes, int N, int W, int D, int F, mmt_stream_t stream);
+/* dout (N, F) -> dweight (F, D, 2), dbias (F).  There is no dx: the windows are input data (the reference never
+ * differentiates them either). */
+int mmt_convpool_backward(const float* x, const float* dout, const int32_t* argmax, float* dweight, float* dbias,
+                          void* workspace, size_t workspace_bytes, int N, int W, int D, int F, mmt_stream_t stream);
+
 /* ---- Test hook: the keep-mask (1 = kept) of dropout stream `stream_id` for indices [0,n) under (p, seed), and the
  * scale applied to kept values (host pointer, may be NULL).  Streams used by the encoder stack for layer l:
  * 4l+0 attention probabilities, index ((b*h+head)*Tp + q)*Tp + key (Tp = T rounded up to 32; pass attn_Tp = Tp,

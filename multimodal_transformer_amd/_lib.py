@@ -43,6 +43,9 @@ SIGNATURES = {
     "mmt_mfn_mem_scan_workspace_bytes": (_SZ, []),
     "mmt_mfn_mem_scan_forward": (_I, [_P] * 9 + [_SZ] + [_I] * 4 + [_F, _U64, _P]),
     "mmt_mfn_mem_scan_backward": (_I, [_P] * 11 + [_SZ] + [_I] * 4 + [_F, _P]),
+    "mmt_convpool_workspace_bytes": (_SZ, [_I] * 4),
+    "mmt_convpool_forward": (_I, [_P] * 6 + [_SZ] + [_I] * 4 + [_P]),
+    "mmt_convpool_backward": (_I, [_P] * 6 + [_SZ] + [_I] * 4 + [_P]),
     "mmt_debug_dropout_mask": (_I, [_F, _U64, _c.c_uint32, _U64, _c.c_uint32, _P, _P, _P]),
 }
 

@@ -14,6 +14,7 @@
 #include "attn.h"
 #include "misc_kernels.h"
 #include "scan.h"
+#include "convpool.h"
 
 // ------------------------------------------------------------------------------------ error plumbing
 static thread_local char g_err[512] = "";
@@ -31,14 +32,14 @@ static int fail(int code, const char* fmt, ...) {
 // dominant kernel's average duration on the stream the kernels really run on.
 enum Site { S_PREP = 0, S_LN1_QKV, S_ATTN_FWD, S_OUTPROJ, S_LN2_FFN1, S_FFN2, S_LN_FWD, S_LN_BWD, S_BWD_FFN2, S_BWD_FFN1_LN2,
             S_BWD_OUTPROJ, S_ATTN_BWD, S_DQ_FINISH, S_BWD_QKV_LN1, S_WGRAD, S_FINALIZE, S_OTHER,
-            S_LINEAR_FWD, S_LINEAR_BWD_DX, S_LINEAR_WGRAD, S_LSTM_FWD, S_LSTM_BWD, S_MEM_FWD, S_MEM_BWD, S_COUNT };
+            S_LINEAR_FWD, S_LINEAR_BWD_DX, S_LINEAR_WGRAD, S_LSTM_FWD, S_LSTM_BWD, S_MEM_FWD, S_MEM_BWD, S_CONV_FWD, S_CONV_BWD, S_COUNT };
 static const char* const g_site_names[S_COUNT] = {
     "encoder_prep_kernel", "rowgemm<FRAG,LN>:ln1+qkv", "attn_fwd_kernel", "chain:outproj+res>ln2+ffn1>ffn2+res",
     "rowgemm<PLAIN,LN>:ln2+ffn1+relu", "rowgemm<PLAIN>:ffn2+res", "layernorm_fwd_kernel", "layernorm_bwd_kernel",
     "chain:bwd_ffn2>bwd_ffn1+ln2>bwd_outproj->dO", "rowgemm<LNBWD>:bwd_ffn1+ln2", "rowgemm<FRAG>:bwd_outproj->dO", "attn_bwd_dkv_kernel",
     "attn_bwd_dq_kernel", "rowgemm<LNBWD>:bwd_qkv+ln1", "wgrad_kernel", "finalize_kernels", "other",
     "rowgemm<PLAIN>:linear_fwd", "rowgemm<PLAIN>:linear_bwd_dx", "wgrad_kernel:linear", "lstm_scan_fwd_kernel", "lstm_scan_bwd_kernel",
-    "mfn_mem_scan_fwd_kernel", "mfn_mem_scan_bwd_kernel"};
+    "mfn_mem_scan_fwd_kernel", "mfn_mem_scan_bwd_kernel", "convpool_fwd_kernel", "convpool_bwd_kernel"};
 struct ProfRec { int site; hipEvent_t a, b; };
 static bool g_prof = false;
 static ProfRec* g_recs = nullptr;
@@ -840,6 +841,66 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
     }
 #undef MMT_LSTM_BWD
     LAUNCH_CHECK("lstm_scan_bwd_kernel");
+    return MMT_OK;
+}
+
+// ------------------------------------------------------------------------------------ window encoder (conv k=2 + max-pool)
+struct ConvWs { bf16* Wp; float* slab; int FPAD, DP, DPB, nsplit, wins; size_t bytes; };
+static int carve_conv(ConvWs& C, int N, int W, int D, int F, void* base) {
+    if (N <= 0 || W < 2 || D <= 0 || F <= 0) return fail(MMT_EINVAL, "bad shape N=%d W=%d D=%d F=%d", N, W, D, F);
+    if (D % 4) return fail(MMT_EUNSUPPORTED, "window encoder needs a raw feature size divisible by 4 (got %d)", D);
+    C.FPAD = round_up(F, CP_FB); C.DP = round_up(D, CP_KC); C.DPB = round_up(D, CP_DB);
+    const int blocks = (C.DPB / CP_DB) * (C.FPAD / CP_FB);
+    int ns = (512 + blocks - 1) / blocks;                   // ~2 workgroups per CU
+    if (ns > (N + 1) / 2) ns = (N + 1) / 2;
+    if (ns < 1) ns = 1;
+    C.wins = round_up((N + ns - 1) / ns, 2);
+    C.nsplit = (N + C.wins - 1) / C.wins;
+    Carver c(base);
+    C.Wp = c.take<bf16>((size_t)2 * C.FPAD * C.DP);
+    C.slab = c.take<float>((size_t)C.nsplit * 2 * C.FPAD * C.DPB);
+    C.bytes = c.off;
+    return MMT_OK;
+}
+extern "C" size_t mmt_convpool_workspace_bytes(int N, int W, int D, int F) {
+    ConvWs C;
+    return carve_conv(C, N, W, D, F, nullptr) ? 0 : C.bytes;
+}
+
+extern "C" int mmt_convpool_forward(const float* x, const float* weight, const float* bias, float* out, int32_t* argmax,
+                                    void* workspace, size_t workspace_bytes, int N, int W, int D, int F, mmt_stream_t stream) {
+    ConvWs C; int rc = carve_conv(C, N, W, D, F, workspace);
+    if (rc) return rc;
+    if (!x || !weight || !bias || !out || !argmax || !workspace) return fail(MMT_EINVAL, "null pointer argument");
+    if (workspace_bytes < C.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, C.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static bool attr = false;
+    if (!attr) { if ((rc = set_lds_attr(&convpool_fwd_kernel))) return rc; attr = true; }
+    hipLaunchKernelGGL(convpool_prep_kernel, dim3(grid_for((size_t)2 * C.FPAD * C.DP)), dim3(256), 0, st, weight, C.Wp, F, D, C.FPAD, C.DP);
+    LAUNCH_CHECK("convpool_prep_kernel");
+    ProfScope prof(S_CONV_FWD, st);
+    hipLaunchKernelGGL(convpool_fwd_kernel, dim3((N + CP_WIN - 1) / CP_WIN, C.FPAD / CP_FB), dim3(512), convpool_fwd_lds_bytes(), st,
+                       x, C.Wp, bias, out, argmax, N, W, D, C.DP, F, C.FPAD);
+    LAUNCH_CHECK("convpool_fwd_kernel");
+    return MMT_OK;
+}
+
+extern "C" int mmt_convpool_backward(const float* x, const float* dout, const int32_t* argmax, float* dweight, float* dbias,
+                                     void* workspace, size_t workspace_bytes, int N, int W, int D, int F, mmt_stream_t stream) {
+    ConvWs C; int rc = carve_conv(C, N, W, D, F, workspace);
+    if (rc) return rc;
+    if (!x || !dout || !argmax || !dweight || !dbias || !workspace) return fail(MMT_EINVAL, "null pointer argument");
+    if (workspace_bytes < C.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, C.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        ProfScope prof(S_CONV_BWD, st);
+        hipLaunchKernelGGL(convpool_bwd_kernel, dim3(C.DPB / CP_DB, C.nsplit, C.FPAD / CP_FB), dim3(512), convpool_bwd_lds_bytes(), st,
+                           x, dout, argmax, C.slab, N, W, D, F, C.FPAD, C.wins);
+    }
+    LAUNCH_CHECK("convpool_bwd_kernel");
+    hipLaunchKernelGGL(convpool_finish_kernel, dim3(grid_for((size_t)F * D * 2 + F)), dim3(256), 0, st, C.slab, dout, dweight, dbias,
+                       C.nsplit, N, D, F, C.FPAD, C.DPB);
+    LAUNCH_CHECK("convpool_finish_kernel");
     return MMT_OK;
 }
 

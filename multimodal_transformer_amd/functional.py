@@ -247,6 +247,55 @@ def lstm_scan(gx, W_rec, h0=None, c0=None):
     return _LstmScanFn.apply(gx, W_rec, h0, c0)
 
 
+class _ConvPoolFn(torch.autograd.Function):
+    """out = max over positions of Conv1d(D -> F, kernel 2)(window) + bias — the reference's CNN.forward
+    (transformer/SFT/models.py:57-79).  x (N,W,D) is input data: no gradient flows to it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        _lib.require_hip(x, weight, bias)
+        if x.requires_grad:
+            raise NotImplementedError("conv_maxpool: the windows are input data; a gradient w.r.t. them is not implemented "
+                                      "(the reference never asks for one)")
+        x_, w_, b_ = _f32c(x), _f32c(weight), _f32c(bias)
+        N, W, D = x_.shape
+        F_ = w_.shape[0]
+        if w_.shape != (F_, D, 2):
+            raise NotImplementedError("conv_maxpool: weight must be (F, D, 2) = nn.Conv1d(D, F, kernel_size=2).weight, got %s"
+                                      % (tuple(w_.shape),))
+        nbytes = lib.mmt_convpool_workspace_bytes(N, W, D, F_)
+        if nbytes == 0:
+            _lib.check(lib.mmt_convpool_forward(None, None, None, None, None, None, 0, N, W, D, F_, None))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x_.device)
+        out = torch.empty(N, F_, dtype=torch.float32, device=x_.device)
+        arg = torch.empty(N, F_, dtype=torch.int32, device=x_.device)
+        _lib.check(lib.mmt_convpool_forward(_lib.ptr(x_), _lib.ptr(w_), _lib.ptr(b_), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(ws), nbytes,
+                                            N, W, D, F_, _lib.stream_ptr()))
+        ctx.save_for_backward(x_, arg)
+        ctx.dims = (N, W, D, F_, nbytes)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, dout, _darg):
+        lib = _lib.load()
+        x_, arg = ctx.saved_tensors
+        N, W, D, F_, nbytes = ctx.dims
+        g = _f32c(dout)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+        dw = torch.empty(F_, D, 2, dtype=torch.float32, device=g.device)
+        db = torch.empty(F_, dtype=torch.float32, device=g.device)
+        _lib.check(lib.mmt_convpool_backward(_lib.ptr(x_), _lib.ptr(g), _lib.ptr(arg), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), nbytes,
+                                             N, W, D, F_, _lib.stream_ptr()))
+        return None, dw, db
+
+
+def conv_maxpool(x, weight, bias):
+    """x (N,W,D) windows, weight (F,D,2), bias (F) -> (out (N,F), argmax positions (N,F) int32)."""
+    return _ConvPoolFn.apply(x, weight, bias)
+
+
 class _MfnMemScanFn(torch.autograd.Function):
     """mem_all = scan(apre, chat, Wm, W2, b2): the MFN memory recurrence
     (transformer/MFT/multiTransformer.py:221-224) with everything that does not depend on mem batched before."""

@@ -36,7 +36,7 @@ def gen_tensor(name, shape, seed):
         return 0.1 * torch.randn(shape, generator=g)
     if len(shape) == 1:                                   # biases
         return (torch.rand(shape, generator=g) * 2 - 1) * 0.1
-    fan_in = shape[-1]
+    fan_in = shape[-1] if len(shape) == 2 else int(math.prod(shape[1:]))      # conv weights (F, D, k): D*k inputs per output
     gain = 3.0 if (".linears.0." in name or ".linears.1." in name) else 1.0   # peaky attention
     bound = gain / math.sqrt(fan_in)
     return (torch.rand(shape, generator=g) * 2 - 1) * bound
