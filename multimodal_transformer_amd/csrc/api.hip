@@ -875,12 +875,22 @@ extern "C" int mmt_convpool_forward(const float* x, const float* weight, const f
     if (workspace_bytes < C.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, C.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     static bool attr = false;
-    if (!attr) { if ((rc = set_lds_attr(&convpool_fwd_kernel))) return rc; attr = true; }
+    if (!attr) {
+        if ((rc = set_lds_attr(&convpool_fwd_kernel<4>)) || (rc = set_lds_attr(&convpool_fwd_kernel<2>)) ||
+            (rc = set_lds_attr(&convpool_fwd_kernel<1>))) return rc;
+        attr = true;
+    }
     hipLaunchKernelGGL(convpool_prep_kernel, dim3(grid_for((size_t)2 * C.FPAD * C.DP)), dim3(256), 0, st, weight, C.Wp, F, D, C.FPAD, C.DP);
     LAUNCH_CHECK("convpool_prep_kernel");
     ProfScope prof(S_CONV_FWD, st);
-    hipLaunchKernelGGL(convpool_fwd_kernel, dim3((N + CP_WIN - 1) / CP_WIN, C.FPAD / CP_FB), dim3(512), convpool_fwd_lds_bytes(), st,
-                       x, C.Wp, bias, out, argmax, N, W, D, C.DP, F, C.FPAD);
+    const int nwg = (N + CP_WIN - 1) / CP_WIN, nmain = F / CP_FB, rem = F - nmain * CP_FB;
+#define MMT_CONV_FWD(CT, blocks, first) hipLaunchKernelGGL((convpool_fwd_kernel<CT>), dim3(nwg, blocks), dim3(512), convpool_fwd_lds_bytes(CT), st, \
+        x, C.Wp, bias, out, argmax, N, W, D, C.DP, F, C.FPAD, first)
+    if (nmain > 0) MMT_CONV_FWD(4, nmain, 0);
+    if (rem > 128) MMT_CONV_FWD(4, 1, nmain * CP_FB);
+    else if (rem > 64) MMT_CONV_FWD(2, 1, nmain * CP_FB);
+    else if (rem > 0) MMT_CONV_FWD(1, 1, nmain * CP_FB);
+#undef MMT_CONV_FWD
     LAUNCH_CHECK("convpool_fwd_kernel");
     return MMT_OK;
 }
@@ -892,6 +902,8 @@ extern "C" int mmt_convpool_backward(const float* x, const float* dout, const in
     if (!x || !dout || !argmax || !dweight || !dbias || !workspace) return fail(MMT_EINVAL, "null pointer argument");
     if (workspace_bytes < C.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, C.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    static bool attr = false;
+    if (!attr) { if ((rc = set_lds_attr(&convpool_bwd_kernel))) return rc; attr = true; }
     {
         ProfScope prof(S_CONV_BWD, st);
         hipLaunchKernelGGL(convpool_bwd_kernel, dim3(C.DPB / CP_DB, C.nsplit, C.FPAD / CP_FB), dim3(512), convpool_bwd_lds_bytes(), st,

@@ -28,11 +28,11 @@
 #define CP_DB 128                      // raw features per backward workgroup
 #define CP_PS 40                       // backward: positions per transposed row (32 + pad)
 
-__host__ __device__ inline size_t convpool_fwd_lds_bytes() {
-    return (size_t)2 * (CP_WIN * CP_ROWS * CP_LDX + 2 * CP_FB * CP_LDX) * sizeof(bf16);
+__host__ __device__ inline size_t convpool_fwd_lds_bytes(int ct) {      // ct = 32-channel tiles per wave: workgroup = 64*ct channels
+    return (size_t)2 * (CP_WIN * CP_ROWS * CP_LDX + 2 * 64 * ct * CP_LDX) * sizeof(bf16);
 }
 __host__ __device__ inline size_t convpool_bwd_lds_bytes() {
-    return (size_t)2 * 2 * CP_DB * CP_PS * sizeof(bf16);          // [window parity][tap][d][position]
+    return (size_t)2 * 2 * 2 * CP_DB * CP_PS * sizeof(bf16);      // [buffer][window of the pair][tap][d][position]
 }
 
 // weight (F, D, 2) fp32 (nn.Conv1d layout) -> Wp bf16 [2][FPAD][DP], zero padded
@@ -44,29 +44,34 @@ __global__ void convpool_prep_kernel(const float* __restrict__ w, bf16* __restri
     }
 }
 
+// CT = channel tiles (32 wide) per wave: the workgroup covers CFB = 64*CT channels starting at c_first + blockIdx.y*CFB.
+// CT = 4 for the bulk; a narrower instance finishes channel counts that are not a multiple of 256 (F = 300: 256 + 64).
+template <int CT>
 __global__ __launch_bounds__(512) void convpool_fwd_kernel(const float* __restrict__ X, const bf16* __restrict__ Wp,
                                                            const float* __restrict__ bias, float* __restrict__ out,
-                                                           int* __restrict__ arg, int N, int W, int D, int DP, int F, int FPAD) {
+                                                           int* __restrict__ arg, int N, int W, int D, int DP, int F, int FPAD,
+                                                           int c_first) {
+    constexpr int CFB = 64 * CT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Xs = reinterpret_cast<bf16*>(smem);                              // [2][CP_WIN][CP_ROWS][CP_LDX]
-    bf16* Bs = Xs + 2 * CP_WIN * CP_ROWS * CP_LDX;                         // [2][2][CP_FB][CP_LDX]
-    constexpr int XS_STAGE = CP_WIN * CP_ROWS * CP_LDX, BS_STAGE = 2 * CP_FB * CP_LDX;
+    bf16* Bs = Xs + 2 * CP_WIN * CP_ROWS * CP_LDX;                         // [2][2][CFB][CP_LDX]
+    constexpr int XS_STAGE = CP_WIN * CP_ROWS * CP_LDX, BS_STAGE = 2 * CFB * CP_LDX;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int wpair = wave >> 1, chalf = wave & 1;
-    const int n0 = blockIdx.x * CP_WIN, cblk = blockIdx.y * CP_FB;
+    const int n0 = blockIdx.x * CP_WIN, cblk = c_first + blockIdx.y * CFB;
     const int npos = W - 1, nrt = (npos + 31) / 32, nchunk = DP / CP_KC;
 
     // staging tasks of this thread: X: items tid + 512*i over CP_WIN*CP_ROWS*8 float4;  W: 4 items of 8 bf16
     constexpr int XITEMS = CP_WIN * CP_ROWS * (CP_KC / 4), XPER = (XITEMS + 511) / 512;
     f32x4 xr[XPER];
-    bf16x8 wr[4];
+    bf16x8 wr[CT];
 
-    float best[2][4];
-    int bestp[2][4];
+    float best[2][CT];
+    int bestp[2][CT];
 #pragma unroll
     for (int wi = 0; wi < 2; ++wi)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) { best[wi][ct] = -INFINITY; bestp[wi][ct] = 0; }
+        for (int ct = 0; ct < CT; ++ct) { best[wi][ct] = -INFINITY; bestp[wi][ct] = 0; }
 
     for (int rt = 0; rt < nrt; ++rt) {
         auto load_chunk = [&](int ch) {
@@ -81,9 +86,9 @@ __global__ __launch_bounds__(512) void convpool_fwd_kernel(const float* __restri
                 xr[i] = v;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int item = tid + 512 * i;                            // 2 taps * 256 channels * 4 pieces = 2048
-                const int tap = item >> 10, chn = (item >> 2) & 255, c8 = item & 3;
+            for (int i = 0; i < CT; ++i) {
+                const int item = tid + 512 * i;                            // 2 taps * CFB channels * 4 pieces = 512 * CT
+                const int tap = item / (CFB * 4), chn = (item >> 2) % CFB, c8 = item & 3;
                 wr[i] = *reinterpret_cast<const bf16x8*>(Wp + ((size_t)tap * FPAD + cblk + chn) * DP + kc + 8 * c8);
             }
         };
@@ -103,18 +108,18 @@ __global__ __launch_bounds__(512) void convpool_fwd_kernel(const float* __restri
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < CT; ++i) {
                 const int item = tid + 512 * i;
-                const int tap = item >> 10, chn = (item >> 2) & 255, c8 = item & 3;
-                *reinterpret_cast<bf16x8*>(bs + (tap * CP_FB + chn) * CP_LDX + 8 * c8) = wr[i];
+                const int tap = item / (CFB * 4), chn = (item >> 2) % CFB, c8 = item & 3;
+                *reinterpret_cast<bf16x8*>(bs + (tap * CFB + chn) * CP_LDX + 8 * c8) = wr[i];
             }
         };
 
-        f32x16 acc[2][4];
+        f32x16 acc[2][CT];
 #pragma unroll
         for (int wi = 0; wi < 2; ++wi)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[wi][ct][i] = 0.f;
 
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(512) void convpool_fwd_kernel(const float* __restri
             // re-fetches its own chunk into the idle stage): no skippable block may sit between MFMAs and their readers
             load_chunk(ch + 1 < nchunk ? ch + 1 : ch);
             const bf16* xs = Xs + stage * XS_STAGE + (2 * wpair * CP_ROWS + r) * CP_LDX + 8 * hh;
-            const bf16* bs = Bs + stage * BS_STAGE + (chalf * 128 + r) * CP_LDX + 8 * hh;
+            const bf16* bs = Bs + stage * BS_STAGE + (chalf * 32 * CT + r) * CP_LDX + 8 * hh;
 #pragma unroll
             for (int tap = 0; tap < 2; ++tap) {
 #pragma unroll
@@ -138,8 +143,8 @@ __global__ __launch_bounds__(512) void convpool_fwd_kernel(const float* __restri
                     for (int wi = 0; wi < 2; ++wi)
                         a[wi] = *reinterpret_cast<const bf16x8*>(xs + (wi * CP_ROWS + tap) * CP_LDX + ks * 16);
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
-                        const bf16x8 b = *reinterpret_cast<const bf16x8*>(bs + (tap * CP_FB + ct * 32) * CP_LDX + ks * 16);
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const bf16x8 b = *reinterpret_cast<const bf16x8*>(bs + (tap * CFB + ct * 32) * CP_LDX + ks * 16);
 #pragma unroll
                         for (int wi = 0; wi < 2; ++wi) acc[wi][ct] = mfma32(a[wi], b, acc[wi][ct]);
                     }
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(512) void convpool_fwd_kernel(const float* __restri
 #pragma unroll
         for (int wi = 0; wi < 2; ++wi)
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
+            for (int ct = 0; ct < CT; ++ct) {
                 float bv = -INFINITY;
                 int bp = 0;
 #pragma unroll
@@ -177,8 +182,8 @@ __global__ __launch_bounds__(512) void convpool_fwd_kernel(const float* __restri
             const int n = n0 + 2 * wpair + wi;
             if (n >= N) continue;
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                const int c = cblk + chalf * 128 + ct * 32 + r;
+            for (int ct = 0; ct < CT; ++ct) {
+                const int c = cblk + chalf * 32 * CT + ct * 32 + r;
                 if (c < F) {
                     out[(size_t)n * F + c] = best[wi][ct] + bias[c];
                     arg[(size_t)n * F + c] = bestp[wi][ct];
@@ -193,8 +198,8 @@ __global__ __launch_bounds__(512) void convpool_bwd_kernel(const float* __restri
                                                            const int* __restrict__ arg, float* __restrict__ slab,
                                                            int N, int W, int D, int F, int FPAD, int wins_per_split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* XT = reinterpret_cast<bf16*>(smem);                              // [2 window slots][2 taps][CP_DB][CP_PS]
-    constexpr int XT_TAP = CP_DB * CP_PS, XT_WIN = 2 * XT_TAP;
+    bf16* XT = reinterpret_cast<bf16*>(smem);                              // [2 buffers][2 windows][2 taps][CP_DB][CP_PS]
+    constexpr int XT_TAP = CP_DB * CP_PS, XT_WIN = 2 * XT_TAP, XT_BUF = 2 * XT_WIN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int fq = wave >> 1, dhalf = wave & 1;                            // wave tile: f tiles 2fq, 2fq+1; d tiles 2dhalf, 2dhalf+1
     const int d0 = blockIdx.x * CP_DB, cblk = blockIdx.z * CP_FB;
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(512) void convpool_bwd_kernel(const float* __restri
     const int nitems = npairs > 0 ? npairs * nrt : 0;
     float dyn[2][2];                                                       // next item: dy and (arg - row tile base) of this lane's
     int avn[2][2];                                                         // channels, [window of the pair][f tile]
-    auto load_item = [&](int it) {
+    auto load_rows = [&](int it) {
         const int pr = it / nrt, rt = it - pr * nrt;
         const int n = nbeg + 2 * pr + swin;
         const bool ok = n < nend && (d0 + sd) < D;
@@ -233,6 +238,9 @@ __global__ __launch_bounds__(512) void convpool_bwd_kernel(const float* __restri
             if (ok && p < W) v = *reinterpret_cast<const f32x4*>(X + ((size_t)n * W + p) * D + d0 + sd);
             xr[i] = v;
         }
+    };
+    auto load_dy = [&](int it) {
+        const int pr = it / nrt, rt = it - pr * nrt;
 #pragma unroll
         for (int w2 = 0; w2 < 2; ++w2)
 #pragma unroll
@@ -243,8 +251,8 @@ __global__ __launch_bounds__(512) void convpool_bwd_kernel(const float* __restri
                 avn[w2][a] = okf ? arg[(size_t)nn * F + f] - rt * 32 : -1;
             }
     };
-    auto store_item = [&]() {
-        bf16* base = XT + swin * XT_WIN;
+    auto store_item = [&](int buf) {
+        bf16* base = XT + buf * XT_BUF + swin * XT_WIN;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {                                      // raw feature sd + c: positions 4g..4g+3 of both taps
             const f32x2 a0 = {xr[0][c], xr[1][c]}, a1 = {xr[2][c], xr[3][c]};
@@ -259,24 +267,32 @@ __global__ __launch_bounds__(512) void convpool_bwd_kernel(const float* __restri
         }
     };
 
-    if (nitems > 0) load_item(0);
-    for (int it = 0; it < nitems; ++it) {
-        __syncthreads();                                                  // readers of the previous item are done
-        store_item();
-        __syncthreads();
-        float dyc[2][2];
-        int avc[2][2];
+    // Pipeline: rows are fetched two items ahead of the MFMAs (registers), transposed into the idle LDS buffer one item
+    // ahead; dy / argmax one item ahead.  One barrier per item; the loop body has no skippable blocks (clamped re-fetches).
+    float dyc[2][2];
+    int avc[2][2];
+    if (nitems > 0) {
+        load_rows(0);
+        load_dy(0);
+        store_item(0);
+        load_rows(nitems > 1 ? 1 : 0);
 #pragma unroll
         for (int w2 = 0; w2 < 2; ++w2)
 #pragma unroll
             for (int a = 0; a < 2; ++a) { dyc[w2][a] = dyn[w2][a]; avc[w2][a] = avn[w2][a]; }
-        load_item(it + 1 < nitems ? it + 1 : it);                          // next item in flight behind the MFMAs (branch-free)
+    }
+    __syncthreads();
+    for (int it = 0; it < nitems; ++it) {
+        store_item((it + 1) & 1);                                          // rows of item it+1 (readers of that buffer: item it-1, done)
+        load_rows(it + 2 < nitems ? it + 2 : nitems - 1);
+        load_dy(it + 1 < nitems ? it + 1 : it);
+        const bf16* XTb = XT + (it & 1) * XT_BUF;
 #pragma unroll
         for (int w2 = 0; w2 < 2; ++w2) {
             // one-hot A fragments: lane (r, hh) holds channel f, positions rt*32 + ks*16 + 8hh + j
             const float* dyv = dyc[w2];
             const int* av = avc[w2];
-            const bf16* xt = XT + w2 * XT_WIN + (dhalf * 64 + r) * CP_PS + 8 * hh;
+            const bf16* xt = XTb + w2 * XT_WIN + (dhalf * 64 + r) * CP_PS + 8 * hh;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 afr[2];
@@ -300,6 +316,11 @@ __global__ __launch_bounds__(512) void convpool_bwd_kernel(const float* __restri
                     }
             }
         }
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) { dyc[w2][a] = dyn[w2][a]; avc[w2][a] = avn[w2][a]; }
+        __syncthreads();
     }
 
     // D tile: column = lane r = raw feature, rows = channels
