@@ -337,6 +337,50 @@ def main():
                 "value": round(M * nst / el, 1), "unit": "windows/s", "ms_per_step": round(1e3 * el / nst, 4), "launch": mrun.launch,
                 "kernel_ms_per_step": {k: round(v[0] / 3, 4) for k, v in sorted(mp_.items(), key=lambda kv: -kv[1][0])[:8]}}
 
+    # ---- raw windows -> valence: the 3-modality SFT pipeline of transformer/SFT/models.py (CNN k=2 + max-pool + Highway per
+    #      modality, fusion, NLPTransformer) at the configs[3] per-GPU slice, N=1 only.  d_model = 128 as in configs[3].
+    pipeline = None
+    if rank == 0 and world == 1 and not args.no_full_model and args.workload == "C4":
+        from multimodal_transformer_amd import models as MM, multiTransformer as MT
+        torch.manual_seed(1)
+        pm = ["acoustic", "image", "linguistic"]
+        pd = {"acoustic": 88, "image": 1000, "linguistic": 300}          # transformer/SFT/train.py:534
+        pw = {"acoustic": 10, "image": 30, "linguistic": 33}             # frames / tokens per window
+        pmodel = MM.MultiCNNTransformer(pm, pd, device=dev)
+        pmodel.Transformer = MT.NLPTransformer(512, embed_dim=d, h=h, N=N, d_ff=f, dropout=DROPOUT, device=dev)
+        pmodel.train(train)
+        pparams = list(pmodel.parameters())
+        praw = {m: torch.randn(B, T, pw[m], pd[m], generator=g).to(dev) for m in pm}
+        ptgt = torch.rand(B, T, 1, generator=g).to(dev)
+
+        def pipe_step():
+            for p in pparams:
+                p.grad = None
+            loss = ((pmodel(praw, [T] * B, mask) - ptgt) ** 2).sum() / float(B * T)
+            loss.backward()
+
+        prun = Runner(pipe_step, pparams, 1, not args.no_graph, 3)
+        pn = max(5, args.steps // 3)
+        pel = prun.timed(pn)
+        _lib.profile(True)
+        for _ in range(3):
+            pipe_step()
+        torch.cuda.synchronize()
+        pp = _lib.profile_collect()
+        _lib.profile(False)
+        conv_flop = sum(2.0 * M * (pw[m] - 1) * 2 * pd[m] * pmodel.window_embed_size[m] for m in pm)
+        cf = pp.get("convpool_fwd_kernel", (0.0, 1))
+        pipeline = {"model": "MultiCNNTransformer(acoustic 10x88, image 30x1000, linguistic 33x300 raw windows -> CNN+max-pool+Highway -> "
+                             "fusion 812->512 -> NLPTransformer(512, embed_dim=%d)); raw inputs fp32, %.2f GB resident in HBM" %
+                             (d, sum(v.numel() for v in praw.values()) * 4 / 1e9),
+                    "value": round(M * pn / pel, 1), "unit": "windows/s", "ms_per_step": round(1e3 * pel / pn, 4), "launch": prun.launch,
+                    "conv_fwd": {"ms_per_step": round(cf[0] / 3, 4), "algorithmic_tflops": round(conv_flop / (cf[0] / 3 * 1e-3) / 1e12, 1),
+                                 "mfma_frac": round(conv_flop / (cf[0] / 3 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                 "what": "3 launches/step (one per modality): 2*(W-1)*2D*F FLOP per window"},
+                    "kernel_ms_per_step": {k: round(v[0] / 3, 4) for k, v in sorted(pp.items(), key=lambda kv: -kv[1][0])[:6]}}
+        del praw, pmodel, prun
+        torch.cuda.empty_cache()
+
     # ---- whole MFT model at configs[2] (3 modalities, T=300, 32 sequences), N=1 only
     mft = None
     if rank == 0 and world == 1 and not args.no_full_model and args.workload == "C4":
@@ -388,6 +432,8 @@ def main():
             out["with_adam"] = adam
         if full is not None:
             out["full_model"] = full
+        if pipeline is not None:
+            out["raw_pipeline"] = pipeline
         if mft is not None:
             out["mft_model"] = mft
         if not args.no_cpu_baseline:

@@ -845,7 +845,7 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
 }
 
 // ------------------------------------------------------------------------------------ window encoder (conv k=2 + max-pool)
-struct ConvWs { bf16* Wp; float* slab; int FPAD, DP, DPB, nsplit, wins; size_t bytes; };
+struct ConvWs { bf16* Wp; float* slab; float* dbpart; int FPAD, DP, DPB, nsplit, wins; size_t bytes; };
 static int carve_conv(ConvWs& C, int N, int W, int D, int F, void* base) {
     if (N <= 0 || W < 2 || D <= 0 || F <= 0) return fail(MMT_EINVAL, "bad shape N=%d W=%d D=%d F=%d", N, W, D, F);
     if (D % 4) return fail(MMT_EUNSUPPORTED, "window encoder needs a raw feature size divisible by 4 (got %d)", D);
@@ -859,6 +859,7 @@ static int carve_conv(ConvWs& C, int N, int W, int D, int F, void* base) {
     Carver c(base);
     C.Wp = c.take<bf16>((size_t)2 * C.FPAD * C.DP);
     C.slab = c.take<float>((size_t)C.nsplit * 2 * C.FPAD * C.DPB);
+    C.dbpart = c.take<float>((size_t)C.nsplit * C.FPAD);
     C.bytes = c.off;
     return MMT_OK;
 }
@@ -903,15 +904,18 @@ extern "C" int mmt_convpool_backward(const float* x, const float* dout, const in
     if (workspace_bytes < C.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, C.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     static bool attr = false;
-    if (!attr) { if ((rc = set_lds_attr(&convpool_bwd_kernel))) return rc; attr = true; }
+    if (!attr) { if ((rc = set_lds_attr(&convpool_bwd_kernel<true>)) || (rc = set_lds_attr(&convpool_bwd_kernel<false>))) return rc; attr = true; }
     {
         ProfScope prof(S_CONV_BWD, st);
-        hipLaunchKernelGGL(convpool_bwd_kernel, dim3(C.DPB / CP_DB, C.nsplit, C.FPAD / CP_FB), dim3(512), convpool_bwd_lds_bytes(), st,
-                           x, dout, argmax, C.slab, N, W, D, F, C.FPAD, C.wins);
+        const dim3 grid(C.DPB / CP_DB, C.nsplit, C.FPAD / CP_FB);
+        if (W <= 33) hipLaunchKernelGGL(convpool_bwd_kernel<true>, grid, dim3(512), convpool_bwd_lds_bytes(), st,
+                                        x, dout, argmax, C.slab, C.dbpart, N, W, D, F, C.FPAD, C.wins);
+        else hipLaunchKernelGGL(convpool_bwd_kernel<false>, grid, dim3(512), convpool_bwd_lds_bytes(), st,
+                                x, dout, argmax, C.slab, C.dbpart, N, W, D, F, C.FPAD, C.wins);
     }
     LAUNCH_CHECK("convpool_bwd_kernel");
-    hipLaunchKernelGGL(convpool_finish_kernel, dim3(grid_for((size_t)F * D * 2 + F)), dim3(256), 0, st, C.slab, dout, dweight, dbias,
-                       C.nsplit, N, D, F, C.FPAD, C.DPB);
+    hipLaunchKernelGGL(convpool_finish_kernel, dim3(grid_for((size_t)F * D * 2 + F)), dim3(256), 0, st, C.slab, C.dbpart, dweight, dbias,
+                       C.nsplit, D, F, C.FPAD, C.DPB);
     LAUNCH_CHECK("convpool_finish_kernel");
     return MMT_OK;
 }

@@ -193,9 +193,15 @@ __global__ __launch_bounds__(512) void convpool_fwd_kernel(const float* __restri
     }
 }
 
+// (Measured and rejected for the forward kernel: a one-wave-per-SIMD variant with 16 accumulator tiles in AGPRs (spills, 1.4x
+// slower), a shift-only staging index map and branch-free clamped loads (both 1.25x slower on the vision shape than the
+// predicated loads below, same box).)
 // grid (ceil(D/128), nsplit, FPAD/256); block 512.  slab layout [split][tap][FPAD][DPB] with DPB = 128*gridDim.x.
+// ONE_RT: windows of at most 33 rows (every reference shape): item = window pair, no index divisions in the loop
+template <bool ONE_RT>
 __global__ __launch_bounds__(512) void convpool_bwd_kernel(const float* __restrict__ X, const float* __restrict__ dy,
                                                            const int* __restrict__ arg, float* __restrict__ slab,
+                                                           float* __restrict__ dbpart,
                                                            int N, int W, int D, int F, int FPAD, int wins_per_split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* XT = reinterpret_cast<bf16*>(smem);                              // [2 buffers][2 windows][2 taps][CP_DB][CP_PS]
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(512) void convpool_bwd_kernel(const float* __restri
     float dyn[2][2];                                                       // next item: dy and (arg - row tile base) of this lane's
     int avn[2][2];                                                         // channels, [window of the pair][f tile]
     auto load_rows = [&](int it) {
-        const int pr = it / nrt, rt = it - pr * nrt;
+        const int pr = ONE_RT ? it : it / nrt, rt = ONE_RT ? 0 : it - pr * nrt;
         const int n = nbeg + 2 * pr + swin;
         const bool ok = n < nend && (d0 + sd) < D;
 #pragma unroll
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(512) void convpool_bwd_kernel(const float* __restri
         }
     };
     auto load_dy = [&](int it) {
-        const int pr = it / nrt, rt = it - pr * nrt;
+        const int pr = ONE_RT ? it : it / nrt, rt = ONE_RT ? 0 : it - pr * nrt;
 #pragma unroll
         for (int w2 = 0; w2 < 2; ++w2)
 #pragma unroll
@@ -271,6 +277,7 @@ __global__ __launch_bounds__(512) void convpool_bwd_kernel(const float* __restri
     // ahead; dy / argmax one item ahead.  One barrier per item; the loop body has no skippable blocks (clamped re-fetches).
     float dyc[2][2];
     int avc[2][2];
+    float dbacc[2] = {0.f, 0.f};
     if (nitems > 0) {
         load_rows(0);
         load_dy(0);
@@ -287,6 +294,9 @@ __global__ __launch_bounds__(512) void convpool_bwd_kernel(const float* __restri
         load_rows(it + 2 < nitems ? it + 2 : nitems - 1);
         load_dy(it + 1 < nitems ? it + 1 : it);
         const bf16* XTb = XT + (it & 1) * XT_BUF;
+        const float first_rt = (ONE_RT || it % nrt == 0) ? 1.f : 0.f;      // bias gradient: every (window, channel) once
+#pragma unroll
+        for (int a = 0; a < 2; ++a) dbacc[a] += first_rt * (dyc[0][a] + dyc[1][a]);
 #pragma unroll
         for (int w2 = 0; w2 < 2; ++w2) {
             // one-hot A fragments: lane (r, hh) holds channel f, positions rt*32 + ks*16 + 8hh + j
@@ -300,10 +310,11 @@ __global__ __launch_bounds__(512) void convpool_bwd_kernel(const float* __restri
                 for (int a = 0; a < 2; ++a) {
                     const int j = av[a] - ks * 16 - 8 * hh;                // element index inside this fragment, or out of range
                     const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, (bf16)dyv[a]);
+                    const unsigned val = bits << ((j & 1) << 4);           // the value in its half of a dword
+                    const int e0 = j >> 1;                                 // dword index (arithmetic shift: out of range stays so)
                     u32x4_t q;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        q[e] = (j == 2 * e) ? bits : ((j == 2 * e + 1) ? (bits << 16) : 0u);
+                    for (int e = 0; e < 4; ++e) q[e] = (e0 == e) ? val : 0u;
                     afr[a] = __builtin_bit_cast(bf16x8, q);
                 }
 #pragma unroll
@@ -323,6 +334,10 @@ __global__ __launch_bounds__(512) void convpool_bwd_kernel(const float* __restri
         __syncthreads();
     }
 
+    if (blockIdx.x == 0 && dhalf == 0 && hh == 0) {                        // one wave per f-tile pair owns the bias partials
+#pragma unroll
+        for (int a = 0; a < 2; ++a) dbpart[(size_t)blockIdx.y * FPAD + cblk + (2 * fq + a) * 32 + r] = dbacc[a];
+    }
     // D tile: column = lane r = raw feature, rows = channels
     float* sl = slab + (size_t)blockIdx.y * 2 * FPAD * DPB;
 #pragma unroll
@@ -339,9 +354,9 @@ __global__ __launch_bounds__(512) void convpool_bwd_kernel(const float* __restri
                 }
 }
 
-// dweight (F, D, 2) = sum over splits of slab[split][tap][f][d];  dbias[f] = sum_n dy[n][f]
-__global__ void convpool_finish_kernel(const float* __restrict__ slab, const float* __restrict__ dy, float* __restrict__ dweight,
-                                       float* __restrict__ dbias, int nsplit, int N, int D, int F, int FPAD, int DPB) {
+// dweight (F, D, 2) = sum over splits of slab[split][tap][f][d];  dbias[f] = sum over splits of dbpart[split][f]
+__global__ void convpool_finish_kernel(const float* __restrict__ slab, const float* __restrict__ dbpart, float* __restrict__ dweight,
+                                       float* __restrict__ dbias, int nsplit, int D, int F, int FPAD, int DPB) {
     const size_t nw = (size_t)F * D * 2;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nw + F; idx += (size_t)gridDim.x * blockDim.x) {
         if (idx < nw) {
@@ -352,7 +367,7 @@ __global__ void convpool_finish_kernel(const float* __restrict__ slab, const flo
         } else {
             const int f = (int)(idx - nw);
             float s = 0.f;
-            for (int n = 0; n < N; ++n) s += dy[(size_t)n * F + f];
+            for (int sp = 0; sp < nsplit; ++sp) s += dbpart[(size_t)sp * FPAD + f];
             dbias[f] = s;
         }
     }

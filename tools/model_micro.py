@@ -21,6 +21,13 @@ elif kind == "sft":
     model = MT.NLPTransformer(512, embed_dim=128, h=8, device=dev); x = torch.tanh(torch.randn(B, T, 512, device=dev))
 elif kind == "sft256":
     model = MT.NLPTransformer(512, device=dev); x = torch.tanh(torch.randn(B, T, 512, device=dev))
+elif kind == "pipe":
+    from multimodal_transformer_amd import models as MM
+    pd = {"acoustic": 88, "image": 1000, "linguistic": 300}
+    pw = {"acoustic": 10, "image": 30, "linguistic": 33}
+    model = MM.MultiCNNTransformer(mods, pd, device=dev)
+    model.Transformer = MT.NLPTransformer(512, embed_dim=128, h=8, device=dev)
+    x = {m: torch.randn(B, T, pw[m], pd[m], device=dev) for m in mods}
 else:
     model = MT.UniFullTransformer(300, device=dev); x = torch.randn(B, T, 300, device=dev)
 model.train()
@@ -30,7 +37,8 @@ lengths = [T] * B
 params = [p for p in model.parameters()]
 def step():
     for p in params: p.grad = None
-    loss = ((model(x, mask, lengths) - tgt) ** 2).sum() / float(B * T)
+    out = model(x, lengths, mask) if kind == "pipe" else model(x, mask, lengths)
+    loss = ((out - tgt) ** 2).sum() / float(B * T)
     loss.backward()
 for _ in range(3): step()
 torch.cuda.synchronize()
