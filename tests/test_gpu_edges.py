@@ -1,0 +1,108 @@
+"""Edge cases of the path on the GPU (through the C ABI): empty / degenerate sequences, single windows, long sequences,
+shapes the kernels must refuse loudly.  Reference semantics: transformer/MFT/multiTransformer.py:22-34 (mask blanks QUERY rows;
+an all-blank sequence is legal and yields uniform attention everywhere), transformer/SFT/train.py:101-104 (prefix masks)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import recipe as R
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+OUT_RTOL = 2e-2
+RELU_GRAD_RTOL = 1.2e-1
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _encoder(d, h, n, dev, seed=17):
+    from multimodal_transformer_amd import multiTransformer as MT
+    enc = MT.Encoder(MT.EncoderLayer(d, MT.MultiHeadedAttention(h, d), MT.PositionwiseFeedForward(d, R.D_FF, 0.1), 0.1), n)
+    p32 = R.gen_params(R.shapes_of(enc.state_dict()), seed)
+    enc.load_state_dict(p32)
+    return enc.to(dev).eval(), p32
+
+
+def _check_encoder(dev, d, h, n, B, T, lengths, tag):
+    enc, p32 = _encoder(d, h, n, dev)
+    x = R.gen_normal(tag + ":x", (B, T, d), 17)
+    g = R.gen_normal(tag + ":g", (B, T, d), 17)
+    mask = R.prefix_mask(lengths, T)
+    xg = x.to(dev).requires_grad_()
+    y = enc(xg, mask.to(dev))
+    (y * g.to(dev)).sum().backward()
+    p = {k: v.double().clone().requires_grad_() for k, v in p32.items()}
+    xd = x.double().requires_grad_()
+    yo = oracle.encoder_stack(p, "", xd, mask.double(), h)
+    (yo * g.double()).sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(xg.grad).all()
+    r, rdx = rel_l2(y.detach().cpu().numpy(), yo.detach().numpy()), rel_l2(xg.grad.cpu().numpy(), xd.grad.numpy())
+    print("%-22s out %.3e dx %.3e" % (tag, r, rdx))
+    assert r < OUT_RTOL and rdx < RELU_GRAD_RTOL
+    for name, q in enc.named_parameters():
+        assert torch.isfinite(q.grad).all(), name
+
+
+def test_sequence_without_any_valid_window(dev):
+    """lengths may contain 0: every query row of that sequence is blanked; the others are unaffected."""
+    _check_encoder(dev, 128, 8, 2, 3, 40, [40, 0, 17], "edge:len0")
+
+
+def test_all_sequences_empty(dev):
+    _check_encoder(dev, 40, 4, 2, 2, 9, [0, 0], "edge:allempty")
+
+
+@pytest.mark.parametrize("B,T,d,h", [(1, 1, 128, 8), (1, 2, 40, 4), (5, 31, 256, 8), (2, 33, 128, 8), (1, 64, 128, 8), (1, 65, 40, 4)])
+def test_tile_boundaries(dev, B, T, d, h):
+    """T around the 32-window tile size, single sequences / single windows"""
+    lengths = [max(1, T - 3 * i) for i in range(B)]
+    _check_encoder(dev, d, h, 2, B, T, lengths, "edge:%dx%dx%d" % (B, T, d))
+
+
+def test_long_sequence_eval_and_dropout_limit(dev):
+    """T = 2500 runs in eval mode; train-mode attention dropout is limited to T <= 4096 (24-bit pair index) and says so"""
+    from multimodal_transformer_amd import multiTransformer as MT
+    enc, p32 = _encoder(128, 8, 1, dev)
+    T = 2500
+    x = R.gen_normal("edge:long:x", (1, T, 128), 17)
+    mask = R.prefix_mask([T], T)
+    with torch.no_grad():
+        y = enc(x.to(dev), mask.to(dev))
+    yo = oracle.encoder_stack({k: v for k, v in p32.items()}, "", x, mask, 8)
+    assert rel_l2(y.cpu().numpy(), yo.numpy()) < OUT_RTOL
+    enc.train()
+    xl = torch.zeros(1, 4200, 128, device=dev)
+    with pytest.raises(RuntimeError, match="4096"):
+        enc(xl, torch.ones(1, 4200, 1, device=dev))
+
+
+def test_model_batch_of_one_window(dev):
+    """whole SFT model on B=1, T=1 (the LSTM scan and every row kernel with a single row)"""
+    from multimodal_transformer_amd import multiTransformer as MT
+    model = MT.NLPTransformer(512, embed_dim=128, h=8, device=dev)
+    p32 = R.gen_params(R.shapes_of(model.state_dict()), 23)
+    model.load_state_dict(p32)
+    model = model.to(dev).eval()
+    x = torch.tanh(R.gen_normal("edge:one:x", (1, 1, 512), 23))
+    mask = torch.ones(1, 1, 1)
+    y = model(x.to(dev), mask.to(dev), [1])
+    (y.sum()).backward()
+    yo = oracle.nlp_transformer(p32, x, mask, 8)
+    assert abs(float(y.detach()) - float(yo)) < 2e-2 * max(abs(float(yo)), 1e-2)
+    for n, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+def test_refusals(dev):
+    from multimodal_transformer_amd import multiTransformer as MT, functional as F
+    with pytest.raises(AssertionError):
+        MT.MultiHeadedAttention(8, 100)                                   # d_model % h != 0: the reference's assert (:39)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        F.lstm_scan(torch.zeros(3, 2, 4 * 6, device=dev), torch.zeros(24, 6, device=dev))          # H % 4 != 0
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        F.sdpa(torch.zeros(1, 8, 8 * 80, device=dev), torch.zeros(1, 8, 640, device=dev), torch.zeros(1, 8, 640, device=dev), None, 8)  # d_k = 80 > 32
