@@ -51,6 +51,7 @@ def site_flops_per_launch(site, M, T, d, f, n_layers=1):
         "rowgemm<FRAG,LN>:ln1+qkv": 6 * d * d,
         "attn_fwd_kernel": 4 * T * d,                                   # QK^T and PV
         "chain:outproj+res>ln2+ffn1>ffn2+res": 2 * d * d + 4 * d * f,
+        "chain:outproj+res>ln2+ffn1>ffn2+res>ln1+qkv(next)": 2 * d * d + 4 * d * f + 6 * d * d,
         "chain:bwd_ffn2>bwd_ffn1+ln2>bwd_outproj->dO": 4 * d * f + 2 * d * d,
         "attn_bwd_dkv_kernel": 6 * T * d,                               # dV, dP, dK  (S recomputed: no credit)
         "attn_bwd_dq_kernel": 2 * T * d,                                # dQ          (S, dP recomputed: no credit)
@@ -69,6 +70,7 @@ def site_flops_per_launch(site, M, T, d, f, n_layers=1):
 SITE_KERNELS = {          # launch site -> kernel symbol prefix in the rocprofv3 tables
     "attn_fwd_kernel": "attn_fwd_kernel", "attn_bwd_dkv_kernel": "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel": "attn_bwd_dq_kernel",
     "chain:outproj+res>ln2+ffn1>ffn2+res": "encoder_post_attn_fwd_kernel",
+    "chain:outproj+res>ln2+ffn1>ffn2+res>ln1+qkv(next)": "encoder_post_attn_fwd4_kernel",
     "chain:bwd_ffn2>bwd_ffn1+ln2>bwd_outproj->dO": "encoder_pre_attn_bwd_kernel",
     "rowgemm<FRAG,LN>:ln1+qkv": "rowgemm_kernel<1, true>", "rowgemm<LNBWD>:bwd_qkv+ln1": "rowgemm_kernel<2, false>",
     "wgrad_kernel": "wgrad_kernel",

@@ -32,14 +32,15 @@ static int fail(int code, const char* fmt, ...) {
 // dominant kernel's average duration on the stream the kernels really run on.
 enum Site { S_PREP = 0, S_LN1_QKV, S_ATTN_FWD, S_OUTPROJ, S_LN2_FFN1, S_FFN2, S_LN_FWD, S_LN_BWD, S_BWD_FFN2, S_BWD_FFN1_LN2,
             S_BWD_OUTPROJ, S_ATTN_BWD, S_DQ_FINISH, S_BWD_QKV_LN1, S_WGRAD, S_FINALIZE, S_OTHER,
-            S_LINEAR_FWD, S_LINEAR_BWD_DX, S_LINEAR_WGRAD, S_LSTM_FWD, S_LSTM_BWD, S_MEM_FWD, S_MEM_BWD, S_CONV_FWD, S_CONV_BWD, S_COUNT };
+            S_LINEAR_FWD, S_LINEAR_BWD_DX, S_LINEAR_WGRAD, S_LSTM_FWD, S_LSTM_BWD, S_MEM_FWD, S_MEM_BWD, S_CONV_FWD, S_CONV_BWD, S_CHAIN4_FWD, S_COUNT };
 static const char* const g_site_names[S_COUNT] = {
     "encoder_prep_kernel", "rowgemm<FRAG,LN>:ln1+qkv", "attn_fwd_kernel", "chain:outproj+res>ln2+ffn1>ffn2+res",
     "rowgemm<PLAIN,LN>:ln2+ffn1+relu", "rowgemm<PLAIN>:ffn2+res", "layernorm_fwd_kernel", "layernorm_bwd_kernel",
     "chain:bwd_ffn2>bwd_ffn1+ln2>bwd_outproj->dO", "rowgemm<LNBWD>:bwd_ffn1+ln2", "rowgemm<FRAG>:bwd_outproj->dO", "attn_bwd_dkv_kernel",
     "attn_bwd_dq_kernel", "rowgemm<LNBWD>:bwd_qkv+ln1", "wgrad_kernel", "finalize_kernels", "other",
     "rowgemm<PLAIN>:linear_fwd", "rowgemm<PLAIN>:linear_bwd_dx", "wgrad_kernel:linear", "lstm_scan_fwd_kernel", "lstm_scan_bwd_kernel",
-    "mfn_mem_scan_fwd_kernel", "mfn_mem_scan_bwd_kernel", "convpool_fwd_kernel", "convpool_bwd_kernel"};
+    "mfn_mem_scan_fwd_kernel", "mfn_mem_scan_bwd_kernel", "convpool_fwd_kernel", "convpool_bwd_kernel",
+    "chain:outproj+res>ln2+ffn1>ffn2+res>ln1+qkv(next)"};
 struct ProfRec { int site; hipEvent_t a, b; };
 static bool g_prof = false;
 static ProfRec* g_recs = nullptr;
@@ -202,11 +203,15 @@ static int launch_rowgemm(const RowGemmParams& p, hipStream_t st, int site = S_O
     return MMT_OK;
 }
 
-template <typename K>
-static int launch_rowchain(K kernel, RowChain3& ch, bool with_g, int site, const char* name, hipStream_t st) {
-    // LDS geometry shared by the three stages
+static int chain_extra_kp(const RowChain3&) { return 0; }
+static int chain_extra_kp(const RowChain4& ch) { return ch.d.KP; }
+
+template <typename K, typename CH>
+static int launch_rowchain(K kernel, CH& ch, bool with_g, int site, const char* name, hipStream_t st) {
+    // LDS geometry shared by the stages
     int kmax = ch.a.KP > ch.b.KP ? ch.a.KP : ch.b.KP;             // stages reading sm.As: a (global) and whichever of b/c stages via Xs
     if (ch.c.KP > kmax) kmax = ch.c.KP;
+    if (chain_extra_kp(ch) > kmax) kmax = chain_extra_kp(ch);
     ch.lda_max = kmax + 8;
     int fw = 128;
     if (with_g && ch.b.NP > fw) fw = ch.b.NP;                  // LayerNorm-backward epilogue needs the full row
@@ -316,21 +321,30 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
         LAUNCH_CHECK("encoder_prep_kernel");
     }
     const float* xin = x;
+    static const bool fuse_next_qkv = getenv("MMT_NO_CHAIN4") == nullptr;
     for (int l = 0; l < D.N; ++l) {
         const LayerWs& w = W.lw[l];
         const float* P = params + (size_t)l * L.stride();
         const bf16* wp = W.wprep + (size_t)l * L.pstride();
         const float* bp = W.bprep + (size_t)l * L.qstride();
-        {   // LayerNorm 1 + fused Q/K/V projection -> attention operand fragments
+        // LayerNorm 1 + fused Q/K/V projection of layer `ll` -> attention operand fragments.  Layer 0 runs it as its own
+        // kernel; for the later layers it is the fourth stage of the previous layer's post-attention chain.
+        auto qkv_params = [&](int ll, const float* src) {
+            const LayerWs& wl = W.lw[ll];
+            const float* Pl = params + (size_t)ll * L.stride();
             RowGemmParams p = rg_zero();
             p.M = D.M; p.K = d; p.KP = L.DP; p.N = 3 * L.HD; p.NP = L.NQ;
-            p.A = xin; p.lda = d; p.At_out = w.xn1T; p.ldt = D.MP;
-            p.ln_a = P + L.oln(0); p.ln_b = P + L.oln(1); p.eps = eps; p.stats = w.stats1;
-            p.W = wp + L.pWqkv(); p.bias = bp + L.qbqkv();
-            p.fragR[0] = w.QR; p.fragR[1] = w.KR; p.fragR[2] = w.VR;
-            p.fragT[0] = w.QT; p.fragT[1] = w.KT; p.fragT[2] = w.VT;
+            p.A = src; p.lda = d; p.At_out = wl.xn1T; p.ldt = D.MP;
+            p.ln_a = Pl + L.oln(0); p.ln_b = Pl + L.oln(1); p.eps = eps; p.stats = wl.stats1;
+            p.W = W.wprep + (size_t)ll * L.pstride() + L.pWqkv(); p.bias = W.bprep + (size_t)ll * L.qstride() + L.qbqkv();
+            p.fragR[0] = wl.QR; p.fragR[1] = wl.KR; p.fragR[2] = wl.VR;
+            p.fragT[0] = wl.QT; p.fragT[1] = wl.KT; p.fragT[2] = wl.VT;
             p.T = T; p.Tp = D.Tp; p.h = h; p.DKP = L.DKP; p.nwhich = 3;
             p.rowmask = mask; p.qscale = LOG2E / sqrtf((float)L.dk); p.scale_first = 1;
+            return p;
+        };
+        if (l == 0) {
+            RowGemmParams p = qkv_params(0, xin);
             if ((rc = launch_rowgemm<EPI_FRAG, true>(p, st, S_LN1_QKV))) return rc;
         }
         // dropout streams of layer l: 4l+0 attention probabilities (:33), 4l+1 / 4l+3 sublayer outputs (:104), 4l+2 FFN hidden (:20)
@@ -356,7 +370,18 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
                 p.out_f32 = w.xout; p.ldo = d;
                 p.drop = make_drop(dropout_p, seed, 4 * l + 3); }
             ch.ldx = L.DP + 4; ch.lda2 = L.FP + 8;
-            if ((rc = launch_rowchain(encoder_post_attn_fwd_kernel, ch, false, S_OUTPROJ, "encoder_post_attn_fwd_kernel", st))) return rc;
+            if (l + 1 < D.N && fuse_next_qkv) {
+                RowChain4 c4; memset(&c4, 0, sizeof(c4));
+                c4.a = ch.a; c4.b = ch.b; c4.c = ch.c; c4.ldx = ch.ldx; c4.lda2 = ch.lda2;
+                c4.d = qkv_params(l + 1, nullptr);                 // A operand: the x2 tile in LDS
+                if ((rc = launch_rowchain(encoder_post_attn_fwd4_kernel, c4, false, S_CHAIN4_FWD, "encoder_post_attn_fwd4_kernel", st))) return rc;
+            } else {
+                if ((rc = launch_rowchain(encoder_post_attn_fwd_kernel, ch, false, S_OUTPROJ, "encoder_post_attn_fwd_kernel", st))) return rc;
+                if (l + 1 < D.N) {
+                    RowGemmParams p = qkv_params(l + 1, w.xout);
+                    if ((rc = launch_rowgemm<EPI_FRAG, true>(p, st, S_LN1_QKV))) return rc;
+                }
+            }
         }
         xin = w.xout;
     }

@@ -584,11 +584,14 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmPa
 
 // ---- chained stages ------------------------------------------------------------------------------
 struct RowChain3 { RowGemmParams a, b, c; int lda_max, ldf, ldx, lda2; };   // LDS geometry decided by the host
+struct RowChain4 { RowGemmParams a, b, c, d; int lda_max, ldf, ldx, lda2; };
 
-__host__ __device__ inline size_t rowchain_lds_bytes(const RowChain3& ch, bool with_g) {
+template <typename CH>
+__host__ __device__ inline size_t rowchain_lds_bytes(const CH& ch, bool with_g) {
     return (size_t)32 * ch.lda_max * 2 + (size_t)32 * ch.ldf * 4 * (with_g ? 2 : 1) + (size_t)32 * ch.ldx * 4 + (size_t)32 * ch.lda2 * 2;
 }
-__device__ __forceinline__ RowSmem rowchain_carve(char* smem, const RowChain3& ch, bool with_g) {
+template <typename CH>
+__device__ __forceinline__ RowSmem rowchain_carve(char* smem, const CH& ch, bool with_g) {
     RowSmem sm;
     sm.As = reinterpret_cast<bf16*>(smem);
     sm.Fs = reinterpret_cast<float*>(smem + (size_t)32 * ch.lda_max * 2);
@@ -610,6 +613,17 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void encoder_post_attn_fwd_kernel(c
     rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X>(ch.a, sm);
     rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2>(ch.b, sm);
     rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X>(ch.c, sm);
+}
+
+// The same chain followed by the NEXT layer's LayerNorm-1 + Q/K/V projection (its input x2 is already in LDS): every
+// layer but the last.  One launch and one round trip of the residual stream less per layer.
+__global__ __launch_bounds__(MMT_THREADS, 2) void encoder_post_attn_fwd4_kernel(const RowChain4 ch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const RowSmem sm = rowchain_carve(smem, ch, false);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X>(ch.a, sm);
+    rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2>(ch.b, sm);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X>(ch.c, sm);
+    rowgemm_stage<EPI_FRAG, true, ASRC_X, 0>(ch.d, sm);
 }
 
 // Backward, from the layer-output gradient dx2 down to the attention core's operands:
