@@ -869,6 +869,13 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
     return MMT_OK;
 }
 
+#ifdef MMT_PHASE_TIMING
+extern "C" int mmt_debug_set_phase_buffer(void* buf) {
+    unsigned long long* b = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_buf), &b, sizeof(b)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 // ------------------------------------------------------------------------------------ window encoder (conv k=2 + max-pool)
 struct ConvWs { bf16* Wp; float* slab; float* dbpart; int FPAD, DP, DPB, nsplit, wins; size_t bytes; };
 static int carve_conv(ConvWs& C, int N, int W, int D, int F, void* base) {

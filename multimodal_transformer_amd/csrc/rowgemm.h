@@ -17,6 +17,23 @@
 #pragma once
 #include "common.h"
 
+// ---- developer instrumentation (never in the shipped build): per-workgroup cycle stamps at the phase boundaries of a stage.
+#ifdef MMT_PHASE_TIMING
+__device__ unsigned long long* g_phase_buf = nullptr;      // [stage slot 0..3][phase 0..7] accumulated cycles, [32] = samples
+__device__ __forceinline__ void phase_mark(unsigned long long& t_prev, int slot, int phase) {
+    if (threadIdx.x == 0 && g_phase_buf) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        atomicAdd(&g_phase_buf[slot * 8 + phase], now - t_prev);
+        t_prev = now;
+    }
+}
+#define PHASE_DECL unsigned long long t_phase_ = __builtin_readcyclecounter(); const int slot_phase_ = (EPI == EPI_FRAG) ? 0 : (EPI == EPI_LNBWD ? 1 : (LNPRO ? 2 : 3));
+#define PHASE(n) phase_mark(t_phase_, slot_phase_, n)
+#else
+#define PHASE_DECL
+#define PHASE(n)
+#endif
+
 enum { EPI_PLAIN = 0, EPI_FRAG = 1, EPI_LNBWD = 2 };
 
 struct RowGemmParams {
@@ -81,6 +98,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     float* Xs = sm.Xs;
     const int m0 = blockIdx.x * 32;
     const int l15 = lane & 15, lq = lane >> 4;
+    PHASE_DECL
 
     // W fragments of the first chunk's first two k-blocks go in flight NOW: their L2 latency overlaps the A-tile staging
     bf16x8 b00, b01, b10, b11, n00, n01, n10, n11;
@@ -193,6 +211,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         }
     }
     __syncthreads();
+    PHASE(0);                                                 // A tile staged (LayerNorm prologue included)
 
     if (p.At_out) {   // T-layout copy of the bf16 tile: task = (feature k, group of 8 rows)
         for (int task = tid; task < KP * 4; task += MMT_THREADS) {
@@ -207,6 +226,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         }
     }
 
+    PHASE(1);                                                 // T-layout copy of the A tile
     // ------------------------------------------------------------------ 2. chunks of 128 columns
     for (int n0 = 0; n0 < NP; n0 += 128) {
         const int nb = n0 + wave * 32;
@@ -254,8 +274,9 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                     for (int r = 0; r < 4; ++r)
                         Fs[(mt * 16 + 4 * lq + r) * ldf + cbase + nt * 16] = acc[mt][nt][r];
         }
-        if (EPI == EPI_LNBWD) continue;
+        if (EPI == EPI_LNBWD) { PHASE(2); continue; }
         __syncthreads();
+        PHASE(2);                                             // k-loop + accumulators parked
 
         // -------------------------------------------------------------- 3. row-wise epilogue (chunk)
         if (EPI == EPI_PLAIN) {
@@ -447,6 +468,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             }
         }
         __syncthreads();
+        PHASE(3);                                             // chunk epilogue (PLAIN / FRAG)
     }
 
     // ------------------------------------------------------------------ LayerNorm backward epilogue
@@ -566,6 +588,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             }
         }
         __syncthreads();
+        PHASE(4);                                             // LayerNorm-backward epilogue + column partials
     }
 }
 
