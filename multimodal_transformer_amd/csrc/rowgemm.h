@@ -214,8 +214,10 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     PHASE(0);                                                 // A tile staged (LayerNorm prologue included)
 
     if (p.At_out) {   // T-layout copy of the bf16 tile: task = (feature k, group of 8 rows)
+        // row group fastest: the 4 lanes of one feature write its 32 windows = 64 contiguous bytes (feature fastest made every
+        // lane's 16 bytes a separate write transaction)
         for (int task = tid; task < KP * 4; task += MMT_THREADS) {
-            const int k = task % KP, rg = task / KP, mb = m0 + rg * 8;
+            const int rg = task & 3, k = task >> 2, mb = m0 + rg * 8;
             if (mb >= M) continue;
             bf16x8 v;
 #pragma unroll
@@ -376,7 +378,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
                     const int task = tid + it * MMT_THREADS;
-                    const int c = task & 127, rg = task >> 7, n = n0 + c, mb = m0 + rg * 8;
+                    const int rg = task & 3, c = task >> 2, n = n0 + c, mb = m0 + rg * 8;       // row group fastest: 64-byte runs
                     if (n >= NP || mb >= M) continue;
                     bf16x8 v;
 #pragma unroll
