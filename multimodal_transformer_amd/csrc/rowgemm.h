@@ -427,7 +427,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                     v *= sc[it];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[i] = (bf16)v[i];
-                    *reinterpret_cast<bf16x4*>(p.fragR[wi] + bh * szR + fragR_index(t, e, p.DKP)) = o;
+                    if (!fastT) *reinterpret_cast<bf16x4*>(p.fragR[wi] + bh * szR + fragR_index(t, e, p.DKP)) = o;
                     if (!fastT) {
                         bf16* dT = p.fragT[wi] + bh * szT;
 #pragma unroll
@@ -452,7 +452,26 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             }
             if (fastT) {
                 __syncthreads();
-                // task = (group of 4 consecutive rows, column): 4 column reads -> one 8-byte store into the T layout
+                // The tile now holds the final bf16-rounded values.  Both fragment layouts are written with lanes laid along
+                // the direction that is contiguous in memory (8-byte stores with the lanes across columns cost one write
+                // transaction per lane: 2.5 M transactions per QKV launch at C4):
+                //  R layout [tile][e>>3][t&31][e&7]: lanes across the 32 windows -> 16 bytes per lane, 512-byte runs
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int q = tid + it * MMT_THREADS, rr = q & 31, cc = q >> 5, nn = n0 + 8 * cc, mm = m0 + rr;
+                    if (nn < p.nwhich * HD && mm < M) {
+                        const int wj = nn / HD, rj = nn - wj * HD, hj = rj / p.DKP, ej = rj - hj * p.DKP;
+                        const int b = mm / p.T, t = mm - b * p.T;
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(Fs + rr * ldf + 8 * cc);
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(Fs + rr * ldf + 8 * cc + 4);
+                        bf16x8 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { o[i] = (bf16)lo[i]; o[4 + i] = (bf16)hi[i]; }
+                        *reinterpret_cast<bf16x8*>(p.fragR[wj] + (size_t)(b * p.h + hj) * szR + fragR_index(t, ej, p.DKP)) = o;
+                    }
+                }
+                //  T layout [tile][s][hh][e][j]: lanes across the columns (e); the 8 j of a 16-byte piece are windows
+                //  t..t+3 and t+8..t+11, i.e. row groups rg and rg+2 of this tile when both lie in it and in the sequence
                 const int c = tid & 127, nn = n0 + c;
                 if (nn < p.nwhich * HD) {
                     const int wj = nn / HD, rj = nn - wj * HD, hj = rj / p.DKP, ej = rj - hj * p.DKP;
@@ -461,10 +480,20 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                         const int rg = (tid >> 7) + 2 * it, mg = m0 + 4 * rg;
                         if (mg >= M) continue;
                         const int b = mg / p.T, t = mg - b * p.T;
+                        const bool second = (t >> 3) & 1;                    // this row group is the j = 4..7 half of its piece
+                        if (second && rg >= 2) continue;                     // written by row group rg-2 (same tile, same sequence)
+                        bf16* dst = p.fragT[wj] + (size_t)(b * p.h + hj) * szT + fragT_index(t, ej);
                         bf16x4 o;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) o[i] = (bf16)Fs[(4 * rg + i) * ldf + c];
-                        *reinterpret_cast<bf16x4*>(p.fragT[wj] + (size_t)(b * p.h + hj) * szT + fragT_index(t, ej)) = o;
+                        if (!second && rg + 2 < 8 && t + 8 < p.T) {
+                            bf16x8 o8;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { o8[i] = o[i]; o8[4 + i] = (bf16)Fs[(4 * rg + 8 + i) * ldf + c]; }
+                            *reinterpret_cast<bf16x8*>(dst) = o8;
+                        } else {
+                            *reinterpret_cast<bf16x4*>(dst) = o;
+                        }
                     }
                 }
             }
