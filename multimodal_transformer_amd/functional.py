@@ -18,7 +18,7 @@ def _f32c(t):
 
 class _EncoderStackFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, mask, flat_params, h, d_ff, n_layers, eps, dropout_p, seed):
+    def forward(ctx, x, mask, flat_params, h, d_ff, n_layers, eps, dropout_p, seed, _needs=False):
         lib = _lib.load()
         _lib.require_hip(x, mask, flat_params)
         x_, m_, p_ = _f32c(x), _f32c(mask), _f32c(flat_params)
@@ -35,7 +35,7 @@ class _EncoderStackFn(torch.autograd.Function):
         y = torch.empty_like(x_)
         _lib.check(lib.mmt_encoder_forward(_lib.ptr(x_), _lib.ptr(m_), _lib.ptr(p_), _lib.ptr(y), _lib.ptr(ws), nbytes,
                                            B, T, d, h, d_ff, n_layers, eps, dropout_p, seed, _lib.stream_ptr()))
-        needs_bwd = any(ctx.needs_input_grad)
+        needs_bwd = _needs or any(ctx.needs_input_grad)
         if needs_bwd:
             ctx.save_for_backward(x_, m_, p_)
             ctx.ws = ws
@@ -64,6 +64,45 @@ class _EncoderStackFn(torch.autograd.Function):
 
 def encoder_stack(x, mask, flat_params, h, d_ff, n_layers, eps=1e-6, dropout_p=0.0, seed=0):
     return _EncoderStackFn.apply(x, mask, flat_params, int(h), int(d_ff), int(n_layers), float(eps), float(dropout_p), int(seed))
+
+
+class _EncoderStackParamsFn(torch.autograd.Function):
+    """Same stack, taking the individual parameter tensors (in the reference's registration order).  The flat buffer is
+    assembled inside ``forward`` and — the point of this variant — ``backward`` hands every parameter a VIEW of ONE flat
+    gradient buffer, so ``p.grad`` of all parameters alias a single allocation: data-parallel training all-reduces that
+    buffer in place with one collective and no staging copies (``parallel.allreduce_gradients``)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, h, d_ff, n_layers, eps, dropout_p, seed, *params):
+        flat = torch.cat([q.detach().reshape(-1) for q in params]).float()
+        ctx.shapes = [tuple(q.shape) for q in params]
+        ctx.inner = _Ctx()
+        y = _EncoderStackFn.forward(ctx.inner, x, mask, flat, h, d_ff, n_layers, eps, dropout_p, seed, _needs=any(ctx.needs_input_grad))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, _, dflat = _EncoderStackFn.backward(ctx.inner, dy)[:3]
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            n = 1
+            for v in shp:
+                n *= v
+            grads.append(dflat[off:off + n].view(shp))
+            off += n
+        return (dx, None, None, None, None, None, None, None) + tuple(grads)
+
+
+class _Ctx:
+    """Minimal stand-in for the autograd context when one Function drives another's static methods."""
+    needs_input_grad = (False, False, False)
+
+    def save_for_backward(self, *t):
+        self.saved_tensors = t
+
+
+def encoder_stack_params(x, mask, params, h, d_ff, n_layers, eps=1e-6, dropout_p=0.0, seed=0):
+    return _EncoderStackParamsFn.apply(x, mask, int(h), int(d_ff), int(n_layers), float(eps), float(dropout_p), int(seed), *params)
 
 
 class _LayerNormFn(torch.autograd.Function):

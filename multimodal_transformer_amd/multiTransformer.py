@@ -189,11 +189,10 @@ class Encoder(nn.Module):
             return self.norm(x)
         l0 = self.layers[0]
         p = l0.sublayer[0].dropout.p if self.training else 0.0
-        flat = torch.cat([q.reshape(-1) for q in self.flat_parameters()])
         self._seed_counter += 1
         seed = (torch.initial_seed() * 1000003 + self._seed_counter) & 0x7FFFFFFFFFFFFFFF if p > 0.0 else 0
-        return F_hip.encoder_stack(x, mask, flat, l0.self_attn.h, l0.feed_forward.w_1.weight.shape[0], len(self.layers),
-                                   eps=self.norm.eps, dropout_p=p, seed=seed)
+        return F_hip.encoder_stack_params(x, mask, self.flat_parameters(), l0.self_attn.h, l0.feed_forward.w_1.weight.shape[0],
+                                          len(self.layers), eps=self.norm.eps, dropout_p=p, seed=seed)
 
 
 def _encoder(embed_dim, h, d_ff, dropout, N):

@@ -25,22 +25,30 @@ def global_window_count(lengths, group=None):
 
 
 def gradient_buckets(params):
-    """Group existing gradients by the buffer they are views of.
+    """Group existing gradients by the allocation they live in.
 
-    Returns (flat_bases, loose): ``flat_bases`` are base tensors whose views are gradients (reduce them in
-    place); ``loose`` are gradients that own their storage (to be coalesced)."""
-    bases, loose, seen = [], [], set()
+    Returns (flat_bases, loose): ``flat_bases`` are 1-D tensors spanning a whole allocation that several gradients are
+    views of (the fused encoder hands all its parameters views of one flat buffer): reduce them in place;
+    ``loose`` are gradients that own their storage (to be coalesced)."""
+    groups, order = {}, []
     for p in params:
         g = p.grad
         if g is None:               # e.g. the reference's dead attn{mod}/ff{mod} parameters (SURVEY §8a A11)
             continue
-        b = g._base
-        if b is not None and b.is_contiguous():
-            if b.data_ptr() not in seen:
-                seen.add(b.data_ptr())
-                bases.append(b)
+        key = g.untyped_storage().data_ptr()
+        if key not in groups:
+            groups[key] = []
+            order.append(key)
+        groups[key].append(g)
+    bases, loose = [], []
+    for key in order:
+        gs = groups[key]
+        st = gs[0].untyped_storage()
+        covered = sum(g.numel() * g.element_size() for g in gs)
+        if len(gs) > 1 and all(g.is_contiguous() for g in gs) and covered == st.nbytes():
+            bases.append(torch.empty(0, dtype=gs[0].dtype, device=gs[0].device).set_(st, 0, (st.nbytes() // gs[0].element_size(),)))
         else:
-            loose.append(g)
+            loose.extend(gs)
     return bases, loose
 
 
@@ -56,8 +64,7 @@ def allreduce_gradients(params, group=None):
     if loose:
         flat = torch._utils._flatten_dense_tensors(loose)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        for g, r in zip(loose, torch._utils._unflatten_dense_tensors(flat, loose)):
-            g.copy_(r)
+        torch._foreach_copy_(loose, list(torch._utils._unflatten_dense_tensors(flat, loose)))    # one multi-tensor kernel
         n += 1
     return n
 

@@ -106,3 +106,20 @@ def test_refusals(dev):
         F.lstm_scan(torch.zeros(3, 2, 4 * 6, device=dev), torch.zeros(24, 6, device=dev))          # H % 4 != 0
     with pytest.raises((RuntimeError, NotImplementedError)):
         F.sdpa(torch.zeros(1, 8, 8 * 80, device=dev), torch.zeros(1, 8, 640, device=dev), torch.zeros(1, 8, 640, device=dev), None, 8)  # d_k = 80 > 32
+
+
+def test_encoder_gradients_share_one_flat_buffer(dev):
+    """data parallelism reduces ONE buffer per step: every parameter gradient of the fused stack must be a view of it"""
+    from multimodal_transformer_amd import parallel
+    enc, _ = _encoder(128, 8, 3, dev)
+    enc.train()
+    x = torch.randn(2, 40, 128, device=dev, requires_grad=True)
+    enc(x, torch.ones(2, 40, 1, device=dev)).sum().backward()
+    params = list(enc.parameters())
+    bases, loose = parallel.gradient_buckets(params)
+    assert len(bases) == 1 and not loose
+    assert bases[0].numel() == sum(p.numel() for p in params)
+    # the views are live: scaling the base scales every .grad
+    before = params[5].grad.clone()
+    bases[0].mul_(2.0)
+    assert torch.equal(params[5].grad, 2.0 * before)
