@@ -440,10 +440,11 @@ def main():
             out["raw_pipeline"] = pipeline
         if mft is not None:
             out["mft_model"] = mft
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # N = 1 only: the other ranks must not wait on 15 s of CPU work
             out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
