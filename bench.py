@@ -228,6 +228,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearsal = os.environ.get("MMT_BENCH_REHEARSAL") == "1"      # developer switch: N ranks on ONE GPU over gloo (code-path check only)
+    if rehearsal:
+        local_rank = 0
     if world == 1 and args.gpus > 1:
         sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
@@ -236,7 +239,10 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from multimodal_transformer_amd import _lib
     cfg = dict(WORKLOADS[args.workload])
