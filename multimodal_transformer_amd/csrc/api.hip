@@ -14,6 +14,7 @@
 #include "attn.h"
 #include "misc_kernels.h"
 #include "scan.h"
+#include "scan256.h"
 #include "convpool.h"
 
 // ------------------------------------------------------------------------------------ error plumbing
@@ -787,7 +788,7 @@ static int carve_lstm(LstmWs& W, int H, void* base) {
     W.HP16 = round_up(H, 16);
     W.HPAD = W.HP16 <= 64 ? 64 : (W.HP16 <= 128 ? 128 : 256);
     Carver c(base);
-    W.Wf = c.take<bf16>((size_t)4 * W.HP16 * W.HPAD); W.Wb = c.take<bf16>((size_t)W.HP16 * 4 * W.HPAD);
+    W.Wf = c.take<bf16>((size_t)4 * W.HP16 * W.HPAD); W.Wb = c.take<bf16>((size_t)(W.HP16 + 16) * 4 * W.HPAD);   // +16 rows: scan256 reads a ragged tile whole
     W.bytes = c.off;
     return MMT_OK;
 }
@@ -817,7 +818,10 @@ extern "C" int mmt_lstm_scan_forward(const float* gx, const float* W_rec, const 
     ProfScope prof(S_LSTM_FWD, st);
 #define MMT_LSTM_FWD(KS, NT, WREG, PF, COOP) hipLaunchKernelGGL((lstm_scan_fwd_kernel<KS, NT, WREG, PF, COOP>), grid, block, 0, st, \
         gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, BT)
-    if (BT <= 2) {              // cooperative step-input loader (see scan.h)
+    if (W.HPAD == 256 && BT == 1) {          // half-resident weights, one sequence per workgroup (scan256.h)
+        hipLaunchKernelGGL((lstm_scan_fwd256_kernel<4, 1>), dim3(B), dim3(64 * ((W.HP16 + 31) / 32)), 0, st,
+                           gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16);
+    } else if (BT <= 2) {       // cooperative step-input loader (see scan.h)
         if (W.HPAD == 64) MMT_LSTM_FWD(2, 256, true, 4, true);
         else if (W.HPAD == 128) MMT_LSTM_FWD(4, 512, true, 4, true);
         else MMT_LSTM_FWD(8, 1024, false, 1, true);
@@ -855,7 +859,13 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
     ProfScope prof(S_LSTM_BWD, st);
 #define MMT_LSTM_BWD(KS4, NT, WREG, PF, COOP) hipLaunchKernelGGL((lstm_scan_bwd_kernel<KS4, NT, WREG, PF, COOP>), grid, block, lds, st, \
         dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, BT)
-    if (coop) {
+    if (W.HPAD == 256 && BT == 1) {
+        static bool attr256 = false;
+        if (!attr256) { if ((rc = set_lds_attr(&lstm_scan_bwd256_kernel<16, 1>))) return rc; attr256 = true; }
+        const size_t lds256 = (size_t)2 * 16 * (4 * 256 + 8) * 2 + (size_t)(2 * 8 * 256 + 8 * 32) * sizeof(float);
+        hipLaunchKernelGGL((lstm_scan_bwd256_kernel<16, 1>), dim3(B), dim3(64 * ((W.HP16 + 31) / 32)), lds256, st,
+                           dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16);
+    } else if (coop) {
         if (W.HPAD == 64) MMT_LSTM_BWD(8, 256, true, 4, true);
         else if (W.HPAD == 128) MMT_LSTM_BWD(16, 512, true, 4, true);
         else MMT_LSTM_BWD(32, 1024, false, 2, true);
