@@ -15,6 +15,7 @@
 #include "misc_kernels.h"
 #include "scan.h"
 #include "scan256.h"
+#include "scan_cluster.h"
 #include "convpool.h"
 
 // ------------------------------------------------------------------------------------ error plumbing
@@ -781,7 +782,7 @@ extern "C" int mmt_linear_backward(const float* dy, const float* x, const float*
 
 
 // ------------------------------------------------------------------------------------ LSTM scan
-struct LstmWs { bf16 *Wf, *Wb; int HP16, HPAD; size_t bytes; };
+struct LstmWs { bf16 *Wf, *Wb; cl_u64* xb; size_t xb_bytes; int HP16, HPAD; size_t bytes; };
 static int carve_lstm(LstmWs& W, int H, void* base) {
     if (H <= 0 || H > 256) return fail(MMT_EUNSUPPORTED, "LSTM hidden size %d not in [4,256]", H);
     if (H % 4) return fail(MMT_EUNSUPPORTED, "LSTM hidden size %d must be a multiple of 4", H);
@@ -789,6 +790,8 @@ static int carve_lstm(LstmWs& W, int H, void* base) {
     W.HPAD = W.HP16 <= 64 ? 64 : (W.HP16 <= 128 ? 128 : 256);
     Carver c(base);
     W.Wf = c.take<bf16>((size_t)4 * W.HP16 * W.HPAD); W.Wb = c.take<bf16>((size_t)(W.HP16 + 16) * 4 * W.HPAD);   // +16 rows: scan256 reads a ragged tile whole
+    W.xb_bytes = W.HPAD == 256 ? (size_t)32 * 2 * CL_NP * 128 * sizeof(cl_u64) : 0;   // exchange granules of the 4-CU scans (<= 32 sequences)
+    W.xb = c.take<cl_u64>(W.xb_bytes / sizeof(cl_u64));
     W.bytes = c.off;
     return MMT_OK;
 }
@@ -818,7 +821,12 @@ extern "C" int mmt_lstm_scan_forward(const float* gx, const float* W_rec, const 
     ProfScope prof(S_LSTM_FWD, st);
 #define MMT_LSTM_FWD(KS, NT, WREG, PF, COOP) hipLaunchKernelGGL((lstm_scan_fwd_kernel<KS, NT, WREG, PF, COOP>), grid, block, 0, st, \
         gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, BT)
-    if (W.HPAD == 256 && BT == 1) {          // half-resident weights, one sequence per workgroup (scan256.h)
+    static const bool no_cluster = getenv("MMT_NO_CLUSTER_SCAN") != nullptr;
+    if (W.HPAD == 256 && B <= 32 && !no_cluster) {       // four CUs per sequence, weights fully register-resident (scan_cluster.h)
+        HIP_TRY(hipMemsetAsync(W.xb, 0, W.xb_bytes, st));
+        hipLaunchKernelGGL((lstm_scan_fwd_cl4_kernel<3>), dim3(32 * ((B + 7) / 8)), dim3(256), 0, st,
+                           gx, W.Wf, h0, c0, h_all, c_all, acts, W.xb, T, B, H, W.HP16);
+    } else if (W.HPAD == 256 && BT == 1) {   // half-resident weights, one sequence per workgroup (scan256.h)
         hipLaunchKernelGGL((lstm_scan_fwd256_kernel<4, 1>), dim3(B), dim3(64 * ((W.HP16 + 31) / 32)), 0, st,
                            gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16);
     } else if (BT <= 2) {       // cooperative step-input loader (see scan.h)
@@ -859,7 +867,12 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
     ProfScope prof(S_LSTM_BWD, st);
 #define MMT_LSTM_BWD(KS4, NT, WREG, PF, COOP) hipLaunchKernelGGL((lstm_scan_bwd_kernel<KS4, NT, WREG, PF, COOP>), grid, block, lds, st, \
         dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, BT)
-    if (W.HPAD == 256 && BT == 1) {
+    static const bool no_cluster = getenv("MMT_NO_CLUSTER_SCAN") != nullptr;
+    if (W.HPAD == 256 && B <= 32 && !no_cluster) {
+        HIP_TRY(hipMemsetAsync(W.xb, 0, W.xb_bytes, st));
+        hipLaunchKernelGGL((lstm_scan_bwd_cl4_kernel<2>), dim3(32 * ((B + 7) / 8)), dim3(256), 0, st,
+                           dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, W.xb, T, B, H, W.HP16);
+    } else if (W.HPAD == 256 && BT == 1) {
         static bool attr256 = false;
         if (!attr256) { if ((rc = set_lds_attr(&lstm_scan_bwd256_kernel<16, 1>))) return rc; attr256 = true; }
         const size_t lds256 = (size_t)2 * 16 * (4 * 256 + 8) * 2 + (size_t)(2 * 8 * 256 + 8 * 32) * sizeof(float);

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(512) void lstm_scan_fwd256_kernel(const float* __re
 
     // weight fragment addresses: gate q, tile ut, k-block ks: row q*HP16 + ubase + 16*ut + l15.  One base pointer and uniform
     // offsets (a ragged last tile reads the rows that follow it in the workspace — valid memory, dead results)
-    const bf16* wbase = Wf + (size_t)(ubase + l15) * S256_KP + 8 * lq;
+    const bf16* wbase = Wf + (size_t)(ubase + l15) * S256_KP + 8 * lq;       // (tile 1 of a ragged last wave reads rows past HP16: finite weights of the next gate / of Wb)
     const size_t gs = (size_t)HP16 * S256_KP;                              // gate stride
     bf16x8 a[4][2][RES];
 #pragma unroll
@@ -174,7 +174,6 @@ __global__ __launch_bounds__(512) void lstm_scan_bwd256_kernel(const float* __re
 
     const int du = lane & 31, ud = ubase + du;
     const bool lived = lane < 32 && ud < H;
-    const float lvd = lived ? 1.f : 0.f;
     const int udc = ud < H ? ud : H - 1;
     // cooperative loader: thread i owns chunk i of the 8H floats [ i f g o | c_t | c_{t-1} | dh_ext | dc_ext ] of a step
     const size_t ostep = (size_t)B * H;
@@ -218,11 +217,11 @@ __global__ __launch_bounds__(512) void lstm_scan_bwd256_kernel(const float* __re
         const float dh = dhd + dhe;
         const float th = tanh_f(ct);
         const float dct = dcd + dce + dh * og * (1.f - th * th);
-        const float dgo = lvd * dh * th * og * (1.f - og);
-        const float dgi = lvd * dct * gg * ig * (1.f - ig);
-        const float dgf = lvd * dct * cp * fg * (1.f - fg);
-        const float dgg = lvd * dct * ig * (1.f - gg * gg);
-        dcd = dct * fg;
+        const float dgo = lived ? dh * th * og * (1.f - og) : 0.f;       // selects: a dead lane's dh may be anything
+        const float dgi = lived ? dct * gg * ig * (1.f - ig) : 0.f;
+        const float dgf = lived ? dct * cp * fg * (1.f - fg) : 0.f;
+        const float dgg = lived ? dct * ig * (1.f - gg * gg) : 0.f;
+        dcd = lived ? dct * fg : 0.f;
         if (lane < 32) {
             bf16* gw = gbuf + cur * 16 * ldg + ud;                         // row 0 = the sequence
             gw[0] = (bf16)dgi; gw[S256_KP] = (bf16)dgf; gw[2 * S256_KP] = (bf16)dgg; gw[3 * S256_KP] = (bf16)dgo;
