@@ -1,0 +1,92 @@
+"""Training-step semantics on the GPU (transformer/SFT/train.py:108-153, :538, :621): MSE-sum loss divided by
+sum(lengths), Adam(lr=1e-4, weight_decay=1e-4), several consecutive steps.  The HIP model and the CPU oracle start from the
+same weights and see the same batches; their loss trajectories and final parameters must agree (dropout off: the reference's
+train-mode dropout stream is not reproducible, its masks are checked separately in test_gpu_dropout.py)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import recipe as R
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _batches(n, B, T, lengths):
+    for i in range(n):
+        x = torch.tanh(R.gen_normal("train:x%d" % i, (B, T, 512), 31))
+        tgt = R.gen_uniform("train:t%d" % i, (B, T, 1), 31) * R.prefix_mask(lengths, T)
+        yield x, tgt
+
+
+def test_adam_steps_follow_the_oracle(dev):
+    from multimodal_transformer_amd import multiTransformer as MT
+    B, T, lengths, steps, lr = 4, 24, [24, 17, 9, 3], 6, 1e-3           # a larger lr than the reference's 1e-4 so that 6 steps move
+    model = MT.NLPTransformer(512, embed_dim=40, h=4, N=2, device=dev)
+    p32 = R.gen_params(R.shapes_of(model.state_dict()), 31)
+    model.load_state_dict(p32)
+    model = model.to(dev).eval()                                         # eval(): dropout off, gradients still flow
+    mask = R.prefix_mask(lengths, T)
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=1e-4)
+    po = {k: v.clone().requires_grad_() for k, v in p32.items()}
+    opt_o = torch.optim.Adam(list(po.values()), lr=lr, weight_decay=1e-4)
+    torch.set_num_threads(4)
+    losses, losses_o = [], []
+    for x, tgt in _batches(steps, B, T, lengths):
+        opt.zero_grad(set_to_none=True)
+        out = model(x.to(dev), mask.to(dev), lengths)
+        loss = ((out - tgt.to(dev)) ** 2).sum() / float(sum(lengths))    # MSELoss(reduction='sum') / sum(lengths)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+        opt_o.zero_grad(set_to_none=True)
+        out_o = oracle.nlp_transformer(po, x, mask, 4)
+        loss_o = oracle.masked_mse_sum_loss(out_o, tgt, lengths)
+        loss_o.backward()
+        opt_o.step()
+        losses_o.append(loss_o.item())
+    print("loss HIP   ", " ".join("%.5f" % v for v in losses))
+    print("loss oracle", " ".join("%.5f" % v for v in losses_o))
+    for a, b in zip(losses, losses_o):
+        assert abs(a - b) <= 2e-2 * abs(b) + 1e-4
+    # Parameters after the steps.  Adam normalises every gradient entry by its own magnitude, so entries whose gradient is
+    # analytically zero (the key-projection biases: softmax is shift invariant) take sign-of-noise steps of full size in BOTH
+    # runs; they are left out, and the accumulated update is compared as one vector.
+    ups, ups_o = [], []
+    for (n, p), (no, q) in zip(model.named_parameters(), po.items()):
+        assert n == no
+        if n.endswith("self_attn.linears.1.bias"):
+            continue
+        ups.append((p.detach().cpu() - p32[n]).reshape(-1))
+        ups_o.append((q.detach() - p32[n]).reshape(-1))
+    dist = rel_l2(torch.cat(ups).numpy(), torch.cat(ups_o).numpy())
+    print("relative distance between the two accumulated updates: %.3e" % dist)
+    assert dist < 0.25        # measured 0.14: Adam turns small gradient differences of small gradients into full-size steps
+
+
+def test_loss_decreases_in_train_mode(dev):
+    """train mode (in-kernel dropout on), reference hyper-parameters except a larger step: fitting one fixed batch"""
+    from multimodal_transformer_amd import multiTransformer as MT
+    torch.manual_seed(1)
+    B, T, lengths = 8, 50, [50, 50, 44, 37, 30, 21, 12, 5]
+    model = MT.NLPTransformer(512, embed_dim=128, h=8, N=2, device=dev).train()
+    mask = R.prefix_mask(lengths, T).to(dev)
+    x = torch.tanh(R.gen_normal("fit:x", (B, T, 512), 5)).to(dev)
+    tgt = (R.gen_uniform("fit:t", (B, T, 1), 5)).to(dev) * mask
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    hist = []
+    for _ in range(60):
+        opt.zero_grad(set_to_none=True)
+        loss = ((model(x, mask, lengths) - tgt) ** 2).sum() / float(sum(lengths))
+        loss.backward()
+        opt.step()
+        hist.append(loss.item())
+    print("loss: first %.4f  last %.4f" % (hist[0], hist[-1]))
+    assert np.isfinite(hist).all() and np.mean(hist[-5:]) < 0.6 * np.mean(hist[:5])
