@@ -412,9 +412,16 @@ def main():
             loss = ((mmodel(xin2, mask2, [Tm] * Bm) - tgt2) ** 2).sum() / float(Bm * Tm)
             loss.backward()
 
-        mrun2 = Runner(mft_step, mparams2, 1, not args.no_graph, 3)
         nst2 = max(5, args.steps // 2)
+        mrun2 = Runner(mft_step, mparams2, 1, not args.no_graph, 3)
         el2 = mrun2.timed(nst2)
+        if mrun2.launch == "hipgraph":
+            # the three modality encoders run on concurrent streams; hipGraph replay serialises part of that concurrency on
+            # ROCm 7.2, so the eager launch can be the faster one: time both, report the better with its label
+            mrun2e = Runner(mft_step, mparams2, 1, False, 2)
+            el2e = mrun2e.timed(nst2)
+            if el2e < el2:
+                el2, mrun2 = el2e, mrun2e
         mft = {"model": "MultiTransformer(acoustic 88, image 256, linguistic 300 -> 256): 3 embeds + 3 encoder stacks (d=256, h=8, N=6) "
                         "on concurrent streams + MFN gate; T=300, 32 sequences (configs[2])",
                "value": round(Bm * Tm * nst2 / el2, 1), "unit": "windows/s", "ms_per_step": round(1e3 * el2 / nst2, 4), "launch": mrun2.launch}
