@@ -660,23 +660,30 @@ __global__ void pad_f32_kernel(const float* __restrict__ src, float* __restrict_
     if (i < np) dst[i] = (i < n && src) ? src[i] : 0.f;
 }
 
-// g = dy * rowscale * relu'(y) -> bf16 row-major [M][NP] and T layout [NP][MP]
+// g = dy * rowscale * act'(y) -> bf16 row-major [M][NP] and T layout [NP][MP].  32x32 tiles through LDS: both outputs are
+// written in contiguous runs (the element-per-thread form wrote the T layout as M*NP separate 2-byte transactions: 31 us per call)
 __global__ void grad_prep_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ rowscale,
                                  int act, bf16* __restrict__ g, bf16* __restrict__ gT, int M, int N, int NP, int MP) {
-    const size_t total = (size_t)M * NP;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int m = (int)(idx / NP), n = (int)(idx % NP);
+    __shared__ float tile[32][33];
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 8 rows per pass
+    for (int r = ty; r < 32; r += 8) {
+        const int m = m0 + r, n = n0 + tx;
         float v = 0.f;
-        if (n < N) {
+        if (m < M && n < N) {
             v = dy[(size_t)m * N + n];
             if (rowscale) v *= rowscale[m];
             if (act == 1) { if (!(y[(size_t)m * N + n] > 0.f)) v = 0.f; }
             else if (act == 2) { const float yy = y[(size_t)m * N + n]; v *= 1.f - yy * yy; }
             else if (act == 3) { const float yy = y[(size_t)m * N + n]; v *= yy * (1.f - yy); }
         }
-        const bf16 o = (bf16)v;
-        g[idx] = o;
-        gT[(size_t)n * MP + m] = o;
+        tile[r][tx] = v;
+        if (m < M) g[(size_t)m * NP + n] = (bf16)v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, m = m0 + tx;
+        if (m < M) gT[(size_t)n * MP + m] = (bf16)tile[tx][r];
     }
 }
 
@@ -750,7 +757,7 @@ extern "C" int mmt_linear_backward(const float* dy, const float* x, const float*
     LinWs W; carve_linear(W, M, K, N, workspace);
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(grad_prep_kernel, dim3(grid_for((size_t)M * W.NP)), dim3(256), 0, st, dy, y, rowscale, act, W.g, W.gT, M, N, W.NP, W.MP);
+    hipLaunchKernelGGL(grad_prep_kernel, dim3((M + 31) / 32, W.NP / 32), dim3(256), 0, st, dy, y, rowscale, act, W.g, W.gT, M, N, W.NP, W.MP);
     LAUNCH_CHECK("grad_prep_kernel");
     if (dx) {
         hipLaunchKernelGGL(pad_cast_kernel, dim3(grid_for((size_t)W.KP * W.NP)), dim3(256), 0, st, Wt, W.WTp, K, N, W.KP, W.NP, 1);
