@@ -119,8 +119,10 @@ class WorkspacePool:
         self._free = {}
         self._home = {}
 
-    def get(self, nbytes, device):
-        key = (str(device), SIDE_LANES.get(int(torch.cuda.current_stream(device).cuda_stream), 0), int(nbytes))
+    def get(self, nbytes, device, tag=None):
+        """``tag`` distinguishes call sites whose workspaces have the same size but a different internal layout (the zero
+        pads of one would be live data of the other)."""
+        key = (str(device), SIDE_LANES.get(int(torch.cuda.current_stream(device).cuda_stream), 0), int(nbytes), tag)
         lst = self._free.get(key)
         buf = lst.pop() if lst else torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
         self._home[buf.data_ptr()] = key

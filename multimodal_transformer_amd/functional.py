@@ -197,13 +197,16 @@ class _LinearFn(torch.autograd.Function):
         if r_ is not None and r_.numel() != M:
             raise ValueError("linear: rowscale must have one entry per row")
         nbytes = lib.mmt_linear_workspace_bytes(M, K, N)
-        ws = torch.zeros(nbytes, dtype=torch.uint8, device=x_.device)
+        ws = _lib.POOL.get(nbytes, x_.device, tag=("linear", M, K, N))     # zero pads survive reuse: the kernels never write them
         y = torch.empty(x_.shape[:-1] + (N,), dtype=torch.float32, device=x_.device)
         _lib.check(lib.mmt_linear_forward(_lib.ptr(x_), _lib.ptr(W_), _lib.ptr(b_), _lib.ptr(r_), _lib.ptr(y), _lib.ptr(ws), nbytes,
                                           M, K, N, act, _lib.stream_ptr()))
-        ctx.save_for_backward(x_, W_, y if act != 0 else None, r_)
         ctx.cfg = (M, K, N, act, nbytes, b is not None)
-        ctx.ws = ws
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x_, W_, y if act != 0 else None, r_)
+            ctx.ws = ws
+        else:
+            _lib.POOL.put(ws)
         return y
 
     @staticmethod
@@ -218,6 +221,7 @@ class _LinearFn(torch.autograd.Function):
         db = torch.empty(N, dtype=torch.float32, device=x_.device) if need_b else None
         _lib.check(lib.mmt_linear_backward(_lib.ptr(g), _lib.ptr(x_), _lib.ptr(W_), _lib.ptr(y_), _lib.ptr(r_), _lib.ptr(dx),
                                            _lib.ptr(dW), _lib.ptr(db), _lib.ptr(ctx.ws), nbytes, M, K, N, act, _lib.stream_ptr()))
+        _lib.POOL.put(ctx.ws)
         ctx.ws = None
         return dx, dW, db, None, None
 
@@ -274,10 +278,11 @@ class _LstmScanFn(torch.autograd.Function):
             hprev = torch.cat([first, h_all[:-1]], dim=0)
             M = T * B
             lb = lib.mmt_linear_workspace_bytes(M, H, 4 * H)
-            lws = torch.zeros(lb, dtype=torch.uint8, device=dev)
+            lws = _lib.POOL.get(lb, dev, tag=("linear", M, H, 4 * H))
             dW = torch.empty_like(W_)
             _lib.check(lib.mmt_linear_backward(_lib.ptr(dgx), _lib.ptr(hprev), _lib.ptr(W_), None, None, None, _lib.ptr(dW), None,
                                                _lib.ptr(lws), lb, M, H, 4 * H, 0, _lib.stream_ptr()))
+            _lib.POOL.put(lws)
         return (dgx, dW, dh0 if (h0_ is not None and ctx.needs_input_grad[2]) else None,
                 dc0 if (c0_ is not None and ctx.needs_input_grad[3]) else None)
 
@@ -382,18 +387,20 @@ class _MfnMemScanFn(torch.autograd.Function):
         mem_prev = torch.cat([torch.zeros(1, B, MD, dtype=torch.float32, device=dev), mem_all[:-1]], dim=0)
         dWm = torch.empty_like(Wm_)
         lb = lib.mmt_linear_workspace_bytes(M, MD, U)
-        lws = torch.zeros(lb, dtype=torch.uint8, device=dev)
+        lws = _lib.POOL.get(lb, dev, tag=("linear", M, MD, U))
         _lib.check(lib.mmt_linear_backward(_lib.ptr(dapre), _lib.ptr(mem_prev), _lib.ptr(Wm_), None, None, None, _lib.ptr(dWm), None,
                                            _lib.ptr(lws), lb, M, MD, U, 0, st))
+        _lib.POOL.put(lws)
         dW2 = torch.empty_like(W2_)
         db2 = torch.empty(2, MD, dtype=torch.float32, device=dev)
         lb2 = lib.mmt_linear_workspace_bytes(M, HG, MD)
         for g in range(2):
             dzg = dz[..., g * MD:(g + 1) * MD].contiguous()
             ug = u_all[..., g * HG:(g + 1) * HG].contiguous()
-            lws2 = torch.zeros(lb2, dtype=torch.uint8, device=dev)
+            lws2 = _lib.POOL.get(lb2, dev, tag=("linear", M, HG, MD))
             _lib.check(lib.mmt_linear_backward(_lib.ptr(dzg), _lib.ptr(ug), _lib.ptr(W2_[g]), None, None, None, _lib.ptr(dW2[g]),
                                                _lib.ptr(db2[g]), _lib.ptr(lws2), lb2, M, HG, MD, 0, st))
+            _lib.POOL.put(lws2)
         return dapre, dchat, dWm, dW2, db2, None, None
 
 
