@@ -123,3 +123,40 @@ def test_encoder_gradients_share_one_flat_buffer(dev):
     before = params[5].grad.clone()
     bases[0].mul_(2.0)
     assert torch.equal(params[5].grad, 2.0 * before)
+
+
+def test_default_model_under_hipgraph_replay(dev):
+    """the reference-default SFT model (embed_dim 256: four-CU LSTM scans with per-launch zeroed exchange granules) captured in
+    a hipGraph and replayed: every replay must reproduce the eager result bit for bit (eval mode)"""
+    from multimodal_transformer_amd import multiTransformer as MT
+    torch.manual_seed(3)
+    B, T = 4, 40
+    model = MT.NLPTransformer(512, device=dev).eval()
+    x = torch.tanh(torch.randn(B, T, 512, device=dev))
+    mask = torch.ones(B, T, 1, device=dev)
+    params = list(model.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        y = model(x, mask, [T] * B)
+        y.sum().backward()
+        return y
+
+    y_ref = step().detach().clone()
+    g_ref = params[0].grad.detach().clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y_static = step()
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y_static, y_ref)
+        assert torch.equal(params[0].grad, g_ref)
