@@ -19,19 +19,20 @@
 
 // ---- developer instrumentation (never in the shipped build): per-workgroup cycle stamps at the phase boundaries of a stage.
 #ifdef MMT_PHASE_TIMING
-__device__ unsigned long long* g_phase_buf = nullptr;      // [stage slot 0..3][phase 0..7] accumulated cycles, [32] = samples
-__device__ __forceinline__ void phase_mark(unsigned long long& t_prev, int slot, int phase) {
-    if (threadIdx.x == 0 && g_phase_buf) {
-        const unsigned long long now = __builtin_readcyclecounter();
-        atomicAdd(&g_phase_buf[slot * 8 + phase], now - t_prev);
-        t_prev = now;
-    }
-}
-#define PHASE_DECL unsigned long long t_phase_ = __builtin_readcyclecounter(); const int slot_phase_ = (EPI == EPI_FRAG) ? 0 : (EPI == EPI_LNBWD ? 1 : (LNPRO ? 2 : 3));
-#define PHASE(n) phase_mark(t_phase_, slot_phase_, n)
+__device__ unsigned long long* g_phase_buf = nullptr;      // [workgroup][stage slot 0..3][phase 0..7] accumulated cycles
+// Stamps are accumulated in registers of thread 0 and flushed once per stage into the workgroup's PRIVATE slots with plain
+// stores: an atomic per mark costs ~7k cycles, and contended atomics at the end of a stage make the next stage wait ~25k
+// cycles for them — both artefacts were larger than the phases they were meant to measure.
+#define PHASE_DECL unsigned long long t_phase_ = __builtin_readcyclecounter(), acc_phase_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+    const int slot_phase_ = (EPI == EPI_FRAG) ? 0 : (EPI == EPI_LNBWD ? 1 : (LNPRO ? 2 : 3));
+#define PHASE(n) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
+    acc_phase_[n] += now_ - t_phase_; t_phase_ = now_; } } while (0)
+#define PHASE_FLUSH do { if (threadIdx.x == 0 && g_phase_buf) { unsigned long long* q_ = g_phase_buf + ((size_t)blockIdx.x * 4 + slot_phase_) * 8; \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) if (acc_phase_[i_]) q_[i_] += acc_phase_[i_]; } } while (0)
 #else
 #define PHASE_DECL
 #define PHASE(n)
+#define PHASE_FLUSH
 #endif
 
 enum { EPI_PLAIN = 0, EPI_FRAG = 1, EPI_LNBWD = 2 };
@@ -621,6 +622,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         __syncthreads();
         PHASE(4);                                             // LayerNorm-backward epilogue + column partials
     }
+    PHASE_FLUSH;
 }
 
 // ---- single stage ------------------------------------------------------------------------------

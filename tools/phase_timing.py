@@ -10,7 +10,8 @@ B, T, d, h = (int(v) for v in (sys.argv[1:5] if len(sys.argv) > 4 else (32, 500,
 dev = torch.device("cuda:0")
 lib = _lib.load()
 raw = ctypes.CDLL(_lib.LIB_PATH)
-buf = torch.zeros(64, dtype=torch.int64, device=dev)
+NWG = (B * T + 31) // 32
+buf = torch.zeros(NWG * 32, dtype=torch.int64, device=dev)
 raw.mmt_debug_set_phase_buffer.argtypes = [ctypes.c_void_p]
 enc = MT.Encoder(MT.EncoderLayer(d, MT.MultiHeadedAttention(h, d), MT.PositionwiseFeedForward(d, 128, 0.1), 0.1), 6).to(dev).train()
 x = torch.randn(B, T, d, device=dev, requires_grad=True)
@@ -21,10 +22,10 @@ torch.cuda.synchronize()
 assert raw.mmt_debug_set_phase_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
 enc(x, mask).sum().backward()
 torch.cuda.synchronize()
-v = buf.cpu().numpy().reshape(8, 8)
+v = buf.cpu().numpy().reshape(NWG, 4, 8).sum(axis=0)
 nwg = (B * T + 31) // 32
 names = ["FRAG stages", "LNBWD stages", "PLAIN+LN stages", "PLAIN stages"]
-ph = ["A staging(+LN)", "T copy of A", "k-loops+park", "chunk epilogues", "LNBWD epilogue"]
+ph = ["A staging(+LN)", "T copy of A", "k-loops+park", "chunk epilogues", "LNBWD epilogue", "-", "-", "-"]
 for s in range(4):
-    tot = v[s, :5].sum()
-    print("%-16s total %8.0f cycles/WG/step: " % (names[s], tot / nwg) + "  ".join("%s %.0f" % (ph[i], v[s, i] / nwg) for i in range(5)))
+    tot = v[s, :8].sum()
+    print("%-16s total %8.0f cycles/WG/step: " % (names[s], tot / nwg) + "  ".join("%s %.0f" % (ph[i], v[s, i] / nwg) for i in range(8) if v[s, i]))
