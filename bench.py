@@ -14,8 +14,14 @@ Primary workload (`value`): the encoder-stack hot path of the SFT configuration 
                  kernels run on): algorithmic FLOPs per launch / average duration vs the dense bf16 MFMA peak;
   cpu_baseline — the CPU oracle (a port of the reference path, fp32 torch CPU) timed on this box's host
                  cores on a bounded sample of the same workload;
+  with_adam    — the same step followed by the reference's optimiser (Adam, foreach) [+ the all-reduce];
   full_model   — (N=1) the whole SFT sequence model NLPTransformer(512 -> d): embed + encoder + LSTM
-                 decoder + MLP + mask, same batch shape, for the end-to-end picture.
+                 decoder + MLP + mask, same batch shape, for the end-to-end picture (SURVEY §8f);
+  raw_pipeline — (N=1) raw windows -> valence: the 3-modality MultiCNNTransformer (CNN k=2 + max-pool + Highway
+                 front-end, fusion, NLPTransformer) with the raw fp32 windows resident in HBM; conv_fwd = the
+                 MFMA fraction of the window-encoder kernel;
+  mft_model    — (N=1) the whole MFT model of configs[2] (3 modality encoders + MFN gate, T=300).
+`roofline.traffic` is read from profiles/r01_pmc_per_kernel.json (separate rocprofv3 --pmc passes of this workload).
 """
 import argparse
 import json
