@@ -625,6 +625,17 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     PHASE_FLUSH;
 }
 
+// Touch every 128-byte line of a later stage's weight matrix at kernel entry (one dword per line, a quarter of the workgroups):
+// the lines come up from MALL into this XCD's L2 while the first stage stages its A tile, so the later stages' W-fragment
+// loads are L2 hits instead of first-touch misses.
+__device__ __forceinline__ void warm_weights(const bf16* W, int NP, int KP) {
+    if ((blockIdx.x & 3) != 0) return;
+    const int lines = (NP * KP) >> 6;                           // 64 bf16 per 128-byte line
+    unsigned acc = 0;
+    for (int l = threadIdx.x; l < lines; l += MMT_THREADS) acc |= *reinterpret_cast<const unsigned*>(W + (size_t)l * 64);
+    asm volatile("" :: "v"(acc));
+}
+
 // ---- single stage ------------------------------------------------------------------------------
 template <int EPI, bool LNPRO>
 __global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmParams p) {
@@ -666,6 +677,7 @@ __device__ __forceinline__ RowSmem rowchain_carve(char* smem, const CH& ch, bool
 __global__ __launch_bounds__(MMT_THREADS, 2) void encoder_post_attn_fwd_kernel(const RowChain3 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, false);
+    warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
     rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X>(ch.a, sm);
     rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2>(ch.b, sm);
     rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X>(ch.c, sm);
@@ -676,6 +688,8 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void encoder_post_attn_fwd_kernel(c
 __global__ __launch_bounds__(MMT_THREADS, 2) void encoder_post_attn_fwd4_kernel(const RowChain4 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, false);
+    warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
+    warm_weights(ch.d.W, ch.d.NP, ch.d.KP);
     rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X>(ch.a, sm);
     rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2>(ch.b, sm);
     rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X>(ch.c, sm);
@@ -689,6 +703,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void encoder_post_attn_fwd4_kernel(
 __global__ __launch_bounds__(MMT_THREADS, 2) void encoder_pre_attn_bwd_kernel(const RowChain3 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, true);
+    warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
     rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_A2>(ch.a, sm);
     rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_X>(ch.b, sm);
     rowgemm_stage<EPI_FRAG, false, ASRC_X, 0>(ch.c, sm);
