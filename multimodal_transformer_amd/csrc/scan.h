@@ -3,10 +3,12 @@
 // LSTM scan (MFN's per-modality nn.LSTMCell, transformer/MFT/multiTransformer.py:152,208, and the SFT
 // decoder's nn.LSTM step, transformer/SFT/multiTransformer.py:471-476).  Only gates += W_rec . h_{t-1} is
 // recurrent; the input projection gx[t] = x_t W_ih^T + b_ih + b_hh is batched over all T by the row GEMM.
-// One workgroup owns 16 sequences (the MFMA N dimension) for the whole scan; wave w owns hidden units
-// [16w, 16w+16) and keeps its slice of W_rec as MFMA A fragments in registers for all T steps, the cell
-// state in registers (fp32), and h crosses waves through a double-buffered bf16 LDS tile: one barrier
-// per step.  Gate order i, f, g, o (torch).
+// One workgroup owns BT <= 16 sequences (columns of the MFMA N dimension; BT is chosen so that the batch
+// spreads over up to 256 CUs — the scan is latency-bound, idle MFMA columns cost nothing) for the whole scan;
+// wave w owns hidden units [16w, 16w+16) and keeps its slice of W_rec as MFMA A fragments in registers for
+// all T steps, the cell state in registers (fp32), and h crosses waves through a double-buffered bf16 LDS
+// tile: one barrier per step.  Gate order i, f, g, o (torch).  H <= 128 here; larger hidden sizes:
+// scan_cluster.h (four CUs per sequence) and scan256.h (half-resident weights).
 #pragma once
 #include "common.h"
 
