@@ -33,7 +33,7 @@ static int fail(int code, const char* fmt, ...) {
 // Optional HIP-event bracket around every launch site (eager mode only), so bench.py can report the
 // dominant kernel's average duration on the stream the kernels really run on.
 enum Site { S_PREP = 0, S_LN1_QKV, S_ATTN_FWD, S_OUTPROJ, S_LN2_FFN1, S_FFN2, S_LN_FWD, S_LN_BWD, S_BWD_FFN2, S_BWD_FFN1_LN2,
-            S_BWD_OUTPROJ, S_ATTN_BWD, S_DQ_FINISH, S_BWD_QKV_LN1, S_WGRAD, S_FINALIZE, S_OTHER,
+            S_BWD_OUTPROJ, S_ATTN_BWD, S_ATTN_BWD_DQ, S_BWD_QKV_LN1, S_WGRAD, S_FINALIZE, S_OTHER,
             S_LINEAR_FWD, S_LINEAR_BWD_DX, S_LINEAR_WGRAD, S_LSTM_FWD, S_LSTM_BWD, S_MEM_FWD, S_MEM_BWD, S_CONV_FWD, S_CONV_BWD, S_CHAIN4_FWD, S_COUNT };
 static const char* const g_site_names[S_COUNT] = {
     "encoder_prep_kernel", "rowgemm<FRAG,LN>:ln1+qkv", "attn_fwd_kernel", "chain:outproj+res>ln2+ffn1>ffn2+res",
@@ -268,7 +268,7 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
     }
     LAUNCH_CHECK("attn_bwd_dkv_kernel");
     {
-        ProfScope prof(S_DQ_FINISH, st);
+        ProfScope prof(S_ATTN_BWD_DQ, st);
 #define MMT_DQ(dkp, dr) hipLaunchKernelGGL((attn_bwd_dq_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, KT_, VR, dOR, lse, delta, rowmask, \
                                            scale, dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, D.B * D.h, drop)
         if (DKP == 16) { if (drop.thr16) MMT_DQ(16, true); else MMT_DQ(16, false); }

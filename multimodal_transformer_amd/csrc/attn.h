@@ -5,7 +5,8 @@
 // Mask semantics of the reference (query-ROW blanking, keys never masked, :29-31,48-50) are applied
 // by the producers/consumers of these operands, not here: a blanked row arrives as Q' = 0, which
 // soft-maxes to exactly 1/T over all T keys like the reference's constant -1e9 row, and its dQ is
-// zeroed by dq_finish_kernel.  Only index masking lives here: keys/queries >= T in the last tile.
+// zeroed by attn_bwd_dq_kernel (which takes the row mask).  Otherwise only index masking lives here:
+// keys/queries >= T in the last tile.
 //
 // Scores are kept in the log2 domain: the producer stores Q' = (x Wq^T + bq) * log2(e)/sqrt(d_k), so
 // P = 2^(S' - L) with L = rowmax + log2(rowsum) saved per query for the backward pass.
@@ -14,7 +15,7 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
-// All three kernels below: grid = (ceil(nt/4), B*h), 4 waves per workgroup, each wave owning one 32-window
+// All three kernels below: a 1-D grid decoded by attn_block() into (tile quad, batch*head), 4 waves per workgroup, each wave owning one 32-window
 // tile of its own and sweeping the other axis.  The swept operand tile (K/V for the forward and dQ kernels,
 // Q/dO/L/delta for the dK-dV kernel) is the same for the four waves, so the workgroup stages it into LDS
 // cooperatively: 2-3 coalesced 16-byte loads per thread, issued one tile AHEAD into registers while the current
