@@ -22,17 +22,18 @@
 // tile computes, written to the other half of a double buffer, one barrier per tile.  The LDS image keeps the
 // global fragment layouts (lane-linear 16-byte pieces), so every wave's MFMA operand is a conflict-free
 // ds_read_b128.  Register budgets stay near 100-130 VGPRs: 3-5 waves share a SIMD.
-template <int NSEG>
+template <int NSEG, int MAXL = 3>
 struct TileStager {
-    // segment i: `pieces[i]` 16-byte pieces per tile, read from base[i] + tile * stride[i] (bf16 elements)
-    static constexpr int MAXL = 3;
-    const bf16* src[MAXL]; int stride[MAXL]; bool on[MAXL]; int lds_piece[MAXL];
+    // segment i: `pieces[i]` 16-byte pieces per tile, read from base[i] + tile * stride[i] (bf16 elements); thread t moves pieces
+    // t, t + 256, ... (MAXL = ceil(total pieces / 256) of them)
+    const bf16* src[MAXL]; int stride[MAXL]; bool on[MAXL]; int tid;
     bf16x8 reg[MAXL];
-    __device__ __forceinline__ void init(const bf16* const* base, const int* pieces, const int* strides, int tid) {
+    __device__ __forceinline__ void init(const bf16* const* base, const int* pieces, const int* strides, int tid_) {
+        tid = tid_;
 #pragma unroll
         for (int l = 0; l < MAXL; ++l) {
             const int p = tid + MMT_THREADS * l;
-            int acc = 0; on[l] = false; src[l] = base[0]; stride[l] = 0; lds_piece[l] = p;
+            int acc = 0; on[l] = false; src[l] = base[0]; stride[l] = 0;
 #pragma unroll
             for (int sg = 0; sg < NSEG; ++sg) {
                 if (!on[l] && p >= acc && p < acc + pieces[sg]) { on[l] = true; src[l] = base[sg] + (size_t)(p - acc) * 8; stride[l] = strides[sg]; }
@@ -46,16 +47,33 @@ struct TileStager {
     }
     __device__ __forceinline__ void store(bf16* lds) const {
 #pragma unroll
-        for (int l = 0; l < MAXL; ++l) if (on[l]) *reinterpret_cast<bf16x8*>(lds + lds_piece[l] * 8) = reg[l];
+        for (int l = 0; l < MAXL; ++l) if (on[l]) *reinterpret_cast<bf16x8*>(lds + (tid + MMT_THREADS * l) * 8) = reg[l];
     }
 };
 
-// per-(batch,head) dropout stream on the probabilities: 32-bit index q*Tp + key, one hash word per key pair
-__device__ __forceinline__ void drop_probs_qlane(f32x16& v, const DropCfg& dc, uint32_t base, int hh) {
+// per-(batch,head) dropout stream on the probabilities.  One hash word serves the key pair (2c, 2c+1) of query q; its index is
+// q*(Tp/2) + c  (< 2^24: host code rejects dropout for Tp > 4096).  The hash is split (common.h) into drop_lin, linear in the index,
+// and the avalanche drop_fin, so a kernel pays ONE add per word for the index:
+//   * query on the lane (forward, dQ): xq = drop_lin(q*Tp/2 + 2hh) is a lane constant, a key tile adds kt*16*C1 (scalar), and the
+//     eight words of a tile sit at compile-time steps from there;
+//   * key on the lane (dK/dV): see attn_bwd_dkv_kernel.
+__device__ __forceinline__ uint32_t drop_xq(const DropCfg& dc, int q, int Tp, int hh) {
+    return drop_lin(dc.s0, (uint32_t)q * ((uint32_t)Tp >> 1) + 2u * (uint32_t)hh);
+}
+template <int QUAD_PERM> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, QUAD_PERM, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t drop_xt(uint32_t xq, int kt) { return xq + (uint32_t)kt * (16u * MMT_DROP_C1); }
+// word of accumulator registers (i, i+1), i even: keys acc32_row(i, hh), +1 of the tile
+__device__ __forceinline__ uint32_t drop_qlane_word(const DropCfg& dc, uint32_t xt, int i) {
+    return drop_fin(xt + (uint32_t)(((i & 3) >> 1) + 4 * (i >> 2)) * MMT_DROP_C1, dc.s1);
+}
+__device__ __forceinline__ void drop_probs_qlane(f32x16& v, const DropCfg& dc, uint32_t xt) {
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {       // registers (i, i+1) hold adjacent keys
-        const uint32_t w = drop_word_idx32(dc, base + (uint32_t)acc32_row(i, hh));
-        v[i] = drop_lo(dc, w, v[i]); v[i + 1] = drop_hi(dc, w, v[i + 1]);
+        const uint32_t w = drop_qlane_word(dc, xt, i);
+        const float m0 = ((w & 0xFFFFu) >= dc.thr16) ? dc.scale : 0.f, m1 = ((w >> 16) >= dc.thr16) ? dc.scale : 0.f;
+        v[i] *= m0; v[i + 1] *= m1;
     }
 }
 
@@ -107,8 +125,9 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
     const bf16* Kb = Kr + (size_t)bh * fragR_elems(Tp, DKP);
     const bf16* Vb = Vt + (size_t)bh * fragT_elems(Tp);
     const DropCfg dc = DROP ? drop_substream(drop, (uint32_t)bh) : drop;       // per-(batch,head) stream
+    const uint32_t xq = DROP ? drop_xq(dc, qtc * 32 + r, Tp, hh) : 0u;
 
-    TileStager<2> stg;
+    TileStager<2, (PK + PV + MMT_THREADS - 1) / MMT_THREADS> stg;
     {
         const bf16* base[2] = {Kb, Vb};
         const int pieces[2] = {PK, PV}, strides[2] = {32 * DKP, 1024};
@@ -168,7 +187,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s[i] = fast_exp2(s[i]); if (!ONES) psum += s[i]; }
         if (!ONES) lrun += psum;
-        if (DROP) drop_probs_qlane(s, dc, (uint32_t)(qtc * 32 + r) * (uint32_t)Tp + (uint32_t)(kt * 32), hh);
+        if (DROP) drop_probs_qlane(s, dc, drop_xt(xq, kt));
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             bf16x8 va = *reinterpret_cast<const bf16x8*>(sv + ((s2 * 2 + hh) * 32 + r) * 8);
@@ -210,7 +229,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
 //     dPc = dO V^T - delta  (same trick with -delta = -rowsum(dO . O))
 //     dS  = P * dPc ;  dV^T += dO^T P ;  dK^T += Q'^T dS     (P, dS accumulators ARE the B operands)
 template <int DKP, bool DROP>
-__global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dkv_kernel(
+__global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_kernel(
         const bf16* __restrict__ Qr, const bf16* __restrict__ Qt, const bf16* __restrict__ Kr, const bf16* __restrict__ Vr,
         const bf16* __restrict__ dOr, const bf16* __restrict__ dOt,
         const float* __restrict__ lse, const float* __restrict__ delta,
@@ -234,7 +253,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dkv_kernel(
     const bf16 *Krb = Kr + offR, *Vrb = Vr + offR;
     const DropCfg dc = DROP ? drop_substream(drop, (uint32_t)bh) : drop;       // per-(batch,head) stream
 
-    TileStager<6> stg;
+    TileStager<6, (TOTAL + MMT_THREADS - 1) / MMT_THREADS> stg;
     {
         const bf16* base[6] = {Qr + offR, dOr + offR, Qt + offT, dOt + offT,
                                reinterpret_cast<const bf16*>(lse + (size_t)bh * Tp), reinterpret_cast<const bf16*>(delta + (size_t)bh * Tp)};
@@ -249,12 +268,22 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dkv_kernel(
         kfr[ss] = *reinterpret_cast<const bf16x8*>(Krb + off);
         vfr[ss] = *reinterpret_cast<const bf16x8*>(Vrb + off);
     }
+    // DKP == 16: the T-layout tiles carry 32 feature rows of which rows 16..31 are zero, so ONE accumulator serves both products:
+    // dO^T as stored fills rows 0..15 (dV^T), and Q^T read with its rows rotated by 16 (lane r fetches row r ^ 16) fills rows 16..31
+    // (dK^T).  16 VGPRs less puts the kernel at 4 waves per SIMD.  DKP == 32 keeps two accumulators.
+    constexpr bool ONEACC = (DKP == 16);
     f32x16 dKacc, dVacc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) { dKacc[j] = 0.f; dVacc[j] = 0.f; }
+    const int rq = ONEACC ? (r ^ 16) : r;
     const bool key_tail = (ktc == nt - 1) && (T & 31);
     const bool key_ok = (ktc * 32 + r) < T;
     const uint32_t kcol = (uint32_t)(ktc * 32 + r);
+    // dropout (see the tile body): lane constants of the word index and of the half-word test
+    const uint32_t hC = ((uint32_t)Tp >> 1) * MMT_DROP_C1;                         // step of one query row
+    const uint32_t par = kcol & 1u;
+    const uint32_t xk = DROP ? drop_lin(dc.s0, (kcol >> 1)) + (uint32_t)(4 * hh + (int)par) * hC : 0u;
+    const uint32_t hmask = par ? 0xFFFF0000u : 0x0000FFFFu, hthr = par ? (dc.thr16 << 16) : dc.thr16;
     stg.store(stage[0]);
     __syncthreads();
 
@@ -275,12 +304,11 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dkv_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl + 8 * g + 4 * hh);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + 8 * g + 4 * hh);
+            f32x4 d4 = {0.f, 0.f, 0.f, 0.f};                                   // DROP: -delta enters after the mask
+            if (!DROP) d4 = *reinterpret_cast<const f32x4*>(sd + 8 * g + 4 * hh);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { s[4 * g + i] = l4[i]; dp[4 * g + i] = d4[i]; }      // both stored negated
         }
-        f32x16 negD;
-        if (DROP) negD = dp;
 #pragma unroll
         for (int ss = 0; ss < KS; ++ss) {
             const int o8 = ((2 * ss + hh) * 32 + r) * 8;
@@ -293,25 +321,31 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dkv_kernel(
             if (QTAIL) pv = (qt * 32 + acc32_row(j, hh) < T) ? pv : 0.f;      // queries >= T do not exist
             s[j] = pv;
         }
-        if (DROP) {
-            // dropped probabilities Pd = P*m/(1-p):  dV^T += dO^T Pd ;  dS = P * ((dO V^T)*m/(1-p) - delta); delta unchanged
-            // pair index (q*Tp + key) >> 1 = q*(Tp/2) + key/2 (Tp is even); this lane's half of the word is fixed by its key parity
-            const uint32_t hTp = (uint32_t)Tp >> 1;
-            const uint32_t p0 = (uint32_t)(qt * 32 + 4 * hh) * hTp + (kcol >> 1);
-            const uint32_t sh = (kcol & 1) * 16;
-            const float keep_scale = dc.scale * kmul;   // keys >= T: multiplier 0
+        if (key_tail) {                                 // wave-uniform, loop-invariant: only the last key tile's wave pays
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const uint32_t w = drop_word(dc.s0, dc.s1, p0 + (uint32_t)((j & 3) + 8 * (j >> 2)) * hTp);
-                const float ms = (((w >> sh) & 0xFFFFu) >= dc.thr16) ? keep_scale : 0.f;
-                dp[j] = (s[j] * kmul) * ((dp[j] - negD[j]) * ms + negD[j]);
-                s[j] *= ms;
+            for (int j = 0; j < 16; ++j) s[j] *= kmul;
+        }
+        if (DROP) {
+            // dropped probabilities Pd = P*m/(1-p):  dV^T += dO^T Pd ;  dS = P * ((dO V^T)*m/(1-p) - delta); delta unchanged.
+            // Word of (query q, this lane's key pair) = fin(xk + q-step): the two lanes of a key pair need the same 16 words, so each
+            // hashes the 8 queries of its own parity (register j = 2k + par) and the pair swaps them by DPP.
+            const uint32_t xt = xk + (uint32_t)qt * (32u * hC);
+            uint32_t mine[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mine[k] = drop_fin(xt + (uint32_t)(((2 * k) & 3) + 8 * (k >> 1)) * hC, dc.s1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + 8 * g + 4 * hh);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = 4 * g + i;
+                    const uint32_t w = (i & 1) ? quad_bcast<0xF5>(mine[j >> 1]) : quad_bcast<0xA0>(mine[j >> 1]);    // from the odd / even lane of the pair
+                    const float ms = ((w & hmask) >= hthr) ? dc.scale : 0.f;
+                    dp[j] = s[j] * fmaf(dp[j], ms, d4[i]);
+                    s[j] *= ms;
+                }
             }
         } else {
-            if (key_tail) {                             // wave-uniform, loop-invariant: only the last key tile's wave pays
-#pragma unroll
-                for (int j = 0; j < 16; ++j) s[j] *= kmul;
-            }
 #pragma unroll
             for (int j = 0; j < 16; ++j) dp[j] *= s[j];
         }
@@ -319,7 +353,8 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dkv_kernel(
         for (int s2 = 0; s2 < 2; ++s2) {
             const int o8 = ((s2 * 2 + hh) * 32 + r) * 8;
             dVacc = mfma32(*reinterpret_cast<const bf16x8*>(sdt + o8), pack8(s, s2), dVacc);
-            dKacc = mfma32(*reinterpret_cast<const bf16x8*>(sqt + o8), pack8(dp, s2), dKacc);
+            if (ONEACC) dVacc = mfma32(*reinterpret_cast<const bf16x8*>(sqt + ((s2 * 2 + hh) * 32 + rq) * 8), pack8(dp, s2), dVacc);
+            else dKacc = mfma32(*reinterpret_cast<const bf16x8*>(sqt + o8), pack8(dp, s2), dKacc);
         }
         if (more) stg.store(stage[(qt + 1) & 1]);
         __syncthreads();
@@ -336,7 +371,10 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dkv_kernel(
         for (int g = 0; g < DKP / 8; ++g) {
             bf16x4 kv, vv;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { kv[j] = (bf16)(dKacc[4 * g + j] * LN2); vv[j] = (bf16)dVacc[4 * g + j]; }
+            for (int j = 0; j < 4; ++j) {
+                kv[j] = (bf16)((ONEACC ? dVacc[8 + 4 * g + j] : dKacc[4 * g + j]) * LN2);      // ONEACC: rows 16 + e sit in registers 8..15
+                vv[j] = (bf16)dVacc[4 * g + j];
+            }
             const int e0 = head * DKP + 8 * g + 4 * hh;
             *reinterpret_cast<bf16x4*>(dkv + m * lddkv + HD + e0) = kv;
             *reinterpret_cast<bf16x4*>(dkv + m * lddkv + 2 * HD + e0) = vv;
@@ -376,8 +414,9 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
     const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
     const bf16 *Qrb = Qr + offR, *dOrb = dOr + offR;
     const DropCfg dc = DROP ? drop_substream(drop, (uint32_t)bh) : drop;       // per-(batch,head) stream
+    const uint32_t xq = DROP ? drop_xq(dc, qtc * 32 + r, Tp, hh) : 0u;
 
-    TileStager<3> stg;
+    TileStager<3, (2 * PR + PT + MMT_THREADS - 1) / MMT_THREADS> stg;
     {
         const bf16* base[3] = {Kr + offR, Vr + offR, Kt + offT};
         const int pieces[3] = {PR, PR, PT}, strides[3] = {32 * DKP, 32 * DKP, 1024};
@@ -409,7 +448,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
         const bf16* skt = sv + PR * 8;
         f32x16 s, dp;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { s[j] = negL; dp[j] = negD; }
+        for (int j = 0; j < 16; ++j) { s[j] = negL; dp[j] = DROP ? 0.f : negD; }      // DROP: -delta enters after the mask
 #pragma unroll
         for (int ss = 0; ss < KS; ++ss) {
             const int o8 = ((2 * ss + hh) * 32 + r) * 8;
@@ -423,13 +462,14 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
             s[j] = pv;
         }
         if (DROP) {
-            const uint32_t base = (uint32_t)(qtc * 32 + r) * (uint32_t)Tp + (uint32_t)(kt * 32);
+            // dS = P * ((dO V^T) * m/(1-p) - delta)
+            const uint32_t xt = drop_xt(xq, kt);
 #pragma unroll
             for (int j = 0; j < 16; j += 2) {
-                const uint32_t w = drop_word_idx32(dc, base + (uint32_t)acc32_row(j, hh));
+                const uint32_t w = drop_qlane_word(dc, xt, j);
                 const float m0 = ((w & 0xFFFFu) >= dc.thr16) ? dc.scale : 0.f, m1 = ((w >> 16) >= dc.thr16) ? dc.scale : 0.f;
-                dp[j] = s[j] * ((dp[j] - negD) * m0 + negD);
-                dp[j + 1] = s[j + 1] * ((dp[j + 1] - negD) * m1 + negD);
+                dp[j] = s[j] * fmaf(dp[j], m0, negD);
+                dp[j + 1] = s[j + 1] * fmaf(dp[j + 1], m1, negD);
             }
         } else {
 #pragma unroll

@@ -80,19 +80,22 @@ __host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m -
 // kept values are scaled by 65536/(65536 - thr16).  A mask is a pure function of (seed, stream, index), so the
 // backward pass regenerates it instead of storing it.
 //   * stream keys (s0, s1) are mixed on the host (splitmix64 of seed and stream id);
-//   * the per-word hash uses only FULL-RATE integer ops (v_mad_u32_u24 + shifts/xors: 9 instructions;
+//   * the per-word hash uses only FULL-RATE integer ops (v_mad_u32_u24, shifts, xor/add: 7 instructions;
 //     v_mul_lo_u32 is quarter rate on CDNA) — the attention kernels are VALU-issue bound and evaluate it per score.
-//     It avalanches a 24-bit pair index; callers fold higher index bits into s0.
+//     It has two parts: drop_lin, LINEAR in the 24-bit pair index (mod 2^32: (a + b) C1 = a C1 + b C1 while a + b < 2^24),
+//     so a kernel that walks indices in a fixed pattern replaces the multiply by one add of a precomputed step
+//     (lane-constant part + wave-uniform part), and drop_fin, the avalanche.  Callers fold higher index bits into s0.
 struct DropCfg { uint32_t thr16; float scale; uint32_t s0, s1; };
 
-__device__ __forceinline__ uint32_t drop_word(uint32_t s0, uint32_t s1, uint32_t pair) {
-    uint32_t x = __umul24(pair, 0xD2B54Bu) + s0;
-    x ^= x >> 15;
-    x ^= s1;
-    x = __umul24(x, 0x9E3779u) + (x >> 24);
-    x ^= x >> 14;
+#define MMT_DROP_C1 0xD2B54Bu
+__device__ __forceinline__ uint32_t drop_lin(uint32_t s0, uint32_t pair) { return __umul24(pair, MMT_DROP_C1) + s0; }
+__device__ __forceinline__ uint32_t drop_fin(uint32_t x, uint32_t s1) {
+    x = (x ^ (x >> 15)) + s1;                       // v_lshrrev, v_xad_u32
+    x = __umul24(x, 0x9E3779u) + (x >> 24);         // v_lshrrev, v_mad_u32_u24
+    x ^= x >> 14;                                   // v_lshrrev, v_xor
     return x;
 }
+__device__ __forceinline__ uint32_t drop_word(uint32_t s0, uint32_t s1, uint32_t pair) { return drop_fin(drop_lin(s0, pair), s1); }
 // strong (3 full multiplies) mixer for once-per-wave key derivation, e.g. the per-(batch,head) attention streams
 __device__ __forceinline__ uint32_t mix32(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t x = c * 0x9E3779B1u + a;
