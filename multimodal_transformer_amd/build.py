@@ -7,14 +7,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmt_hip.so")
 SOURCES = ["api.hip"]
-HEADERS = ["common.h", "rowgemm.h", "attn.h", "misc_kernels.h", "scan.h"]
 
 
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "mmt_hip.h")]
+    headers = [f for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + headers] + [os.path.join(HERE, "..", "include", "mmt_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 

@@ -68,12 +68,33 @@ __device__ __forceinline__ uint32_t drop_xt(uint32_t xq, int kt) { return xq + (
 __device__ __forceinline__ uint32_t drop_qlane_word(const DropCfg& dc, uint32_t xt, int i) {
     return drop_fin(xt + (uint32_t)(((i & 3) >> 1) + 4 * (i >> 2)) * MMT_DROP_C1, dc.s1);
 }
+// Half-word keep selects: (half of w) >= thr16 ? v : 0.  The high half compiles to v_cmp_ge_u32_sdwa + v_cndmask; for the low half
+// hipcc emits an AND plus a 32-bit compare, so that one is written out (v_cmp_le_u16 reads the low 16 bits of its operands).
+__device__ __forceinline__ float keep_lo_sel(uint32_t w, uint32_t thr16, float v) {
+    float r;
+    asm("v_cmp_le_u16 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(r) : "v"(thr16), "v"(w), "v"(v) : "vcc");
+    return r;
+}
+__device__ __forceinline__ float keep_hi_sel(uint32_t w, uint32_t thr16, float v) { return (w >> 16) >= thr16 ? v : 0.f; }
+// all 16 registers = x in eight 64-bit moves (hipcc writes a splat as sixteen v_mov_b32).  The trailing s_nop covers the two
+// wait states an MFMA needs after a VALU write of its SrcC: the hazard recognizer does not see through asm statements.
+__device__ __forceinline__ void fill16(f32x16& v, float x) {
+    const f32x2 xp = {x, x};
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        f32x2 t;
+        if (i < 14) asm volatile("v_mov_b64 %0, %1" : "=v"(t) : "v"(xp));       // volatile: eight separate moves, not one plus copies
+        else asm volatile("v_mov_b64 %0, %1\n\ts_nop 1" : "=v"(t) : "v"(xp));
+        v[i] = t[0]; v[i + 1] = t[1];
+    }
+}
+// zeroes the dropped probabilities; the caller owes the factor 1/(1-p) (the forward applies it once, to the output row)
 __device__ __forceinline__ void drop_probs_qlane(f32x16& v, const DropCfg& dc, uint32_t xt) {
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {       // registers (i, i+1) hold adjacent keys
         const uint32_t w = drop_qlane_word(dc, xt, i);
-        const float m0 = ((w & 0xFFFFu) >= dc.thr16) ? dc.scale : 0.f, m1 = ((w >> 16) >= dc.thr16) ? dc.scale : 0.f;
-        v[i] *= m0; v[i + 1] *= m1;
+        v[i] = keep_lo_sel(w, dc.thr16, v[i]);
+        v[i + 1] = keep_hi_sel(w, dc.thr16, v[i + 1]);
     }
 }
 
@@ -159,9 +180,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
         const bf16* sk = stage[kt & 1];
         const bf16* sv = sk + PK * 8;
         f32x16 s;
-        const float init = (kt == 0) ? 0.f : -mrun;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = init;
+        fill16(s, (kt == 0) ? 0.f : -mrun);
 #pragma unroll
         for (int ss = 0; ss < KS; ++ss)
             s = mfma32(*reinterpret_cast<const bf16x8*>(sk + ((2 * ss + hh) * 32 + r) * 8), qf[ss], s);
@@ -169,6 +188,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[i] = (kt * 32 + acc32_row(i, hh) < T) ? s[i] : -INFINITY;
         }
+        // (no inline asm here: hipcc's hazard recognizer does not count an asm statement as a reader of MFMA results)
         float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
         for (int i = 3; i < 15; i += 2) tmax = fmaxf(fmaxf(tmax, s[i]), s[i + 1]);
@@ -183,10 +203,14 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o[i] *= alpha; s[i] -= dlt; }
         }
-        float psum = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { s[i] = fast_exp2(s[i]); if (!ONES) psum += s[i]; }
-        if (!ONES) lrun += psum;
+        for (int i = 0; i < 16; ++i) s[i] = fast_exp2(s[i]);
+        if (!ONES) {                                    // row sum of the tile in packed adds
+            f32x2 p2 = {s[0], s[1]};
+#pragma unroll
+            for (int i = 2; i < 16; i += 2) { const f32x2 t = {s[i], s[i + 1]}; p2 += t; }
+            lrun += p2[0] + p2[1];
+        }
         if (DROP) drop_probs_qlane(s, dc, drop_xt(xq, kt));
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -203,7 +227,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
     float ltot;
     if (ONES) ltot = __shfl(o[8], r);                  // O^T row 16 = (register 8, lower half): the row sums
     else ltot = lrun + __shfl_xor(lrun, 32);
-    const float inv = 1.0f / ltot;
+    const float inv = (DROP ? dc.scale : 1.0f) / ltot;      // kept probabilities carry 1/(1-p)
     const int t = qt * 32 + r;
     if (t < T) {
         const size_t m = (size_t)b * T + t;
@@ -447,8 +471,11 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
         const bf16* sv = sk + PR * 8;
         const bf16* skt = sv + PR * 8;
         f32x16 s, dp;
+        fill16(s, negL);
+        if (DROP) {                                     // -delta enters after the mask
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { s[j] = negL; dp[j] = DROP ? 0.f : negD; }      // DROP: -delta enters after the mask
+            for (int j = 0; j < 16; ++j) dp[j] = 0.f;
+        } else fill16(dp, negD);
 #pragma unroll
         for (int ss = 0; ss < KS; ++ss) {
             const int o8 = ((2 * ss + hh) * 32 + r) * 8;
@@ -467,7 +494,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
 #pragma unroll
             for (int j = 0; j < 16; j += 2) {
                 const uint32_t w = drop_qlane_word(dc, xt, j);
-                const float m0 = ((w & 0xFFFFu) >= dc.thr16) ? dc.scale : 0.f, m1 = ((w >> 16) >= dc.thr16) ? dc.scale : 0.f;
+                const float m0 = keep_lo_sel(w, dc.thr16, dc.scale), m1 = keep_hi_sel(w, dc.thr16, dc.scale);
                 dp[j] = s[j] * fmaf(dp[j], m0, negD);
                 dp[j + 1] = s[j + 1] * fmaf(dp[j + 1], m1, negD);
             }
