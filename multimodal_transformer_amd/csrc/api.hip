@@ -12,6 +12,7 @@
 #include "common.h"
 #include "rowgemm.h"
 #include "attn.h"
+#include "attn_bwd_fused.h"
 #include "misc_kernels.h"
 #include "scan.h"
 #include "scan256.h"
@@ -258,6 +259,22 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
                            bf16* dqkv, bf16* dqkvT, const EncDims& D, hipStream_t st, DropCfg drop = no_drop()) {
     dim3 grid(attn_grid((D.nt + 3) / 4, D.B * D.h));
     const float scale = 1.0f / sqrtf((float)D.L.dk);
+    static const bool fused = getenv("MMT_NO_FUSED_ATTN_BWD") == nullptr;
+    if (fused && attn_bwd_fused_ok(DKP, D.nt)) {        // one evaluation of P and dS per score: attn_bwd_fused.h
+        static bool configured = false;
+        if (!configured) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            configured = true;
+        }
+        ProfScope prof(S_ATTN_BWD, st);
+#define MMT_FUSED(dr) hipLaunchKernelGGL((attn_bwd_fused16_kernel<dr>), dim3(D.B * D.h), dim3(MMT_FUSED_THREADS), MMT_FUSED_LDS_BYTES, st, \
+                                          QR, QT, KR, KT_, VR, dOR, dOT, lse, delta, rowmask, scale, dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, drop)
+        if (drop.thr16) MMT_FUSED(true); else MMT_FUSED(false);
+#undef MMT_FUSED
+        LAUNCH_CHECK("attn_bwd_fused16_kernel");
+        return MMT_OK;
+    }
     {
         ProfScope prof(S_ATTN_BWD, st);
 #define MMT_DKV(dkp, dr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, QT, KR, VR, dOR, dOT, lse, delta, \

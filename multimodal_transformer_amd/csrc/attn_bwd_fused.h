@@ -1,0 +1,243 @@
+// Attention backward in ONE kernel for d_k <= 16 and 9..16 key tiles (T = 257..512): dQ, dK and dV from a single evaluation of
+// P = 2^(S'-L) and dS = P (dP - delta) per score, instead of once in attn_bwd_dkv_kernel and once more in attn_bwd_dq_kernel
+// (attn.h).  Both of those are VALU-issue bound (exp, the dropout hash, the bf16 converts), so the second evaluation is what the
+// fusion removes; the MFMA work is unchanged.
+//
+// One workgroup of 16 waves owns one (batch, head).  Wave w owns key tile w and keeps dK^T / dV^T of that tile in ONE accumulator
+// (attn_bwd_dkv_kernel's d_k = 16 trick); all waves sweep the query tiles together, sharing the staged Q / dO / L / delta tile like
+// the 4-wave kernels do.  Per query tile each wave also forms its 32-key share of dQ^T = K^T dS^T:
+//   * dS sits in the accumulator layout with the key on the lane; the dQ product contracts over keys, so dS goes through a
+//     wave-private LDS patch [32 queries][32 keys] bf16 (16 ds_write_b16 + 2 ds_read_b128 per lane) to become a B operand, the key
+//     columns permuted to the order the T-layout K^T tile presents them;
+//   * the fp32 partial (8 registers for d_k <= 16) overwrites the patch, and after the tile's barrier all 16 waves sum the 16
+//     partials in a fixed order (bit-reproducible, no atomics), apply 1/sqrt(d_k) and the query-row mask and store both layouts of
+//     dQ — each wave 32 outputs per layout, coalesced.  Patch/partial regions are double-buffered by tile parity, so one barrier
+//     per tile orders everything.
+// Registers: 16 waves per CU means 128 VGPRs per wave; the kernel is written to fit (the own tile's K, V and K^T fragments live in
+// LDS instead of registers, the staging ring needs one 16-byte piece per thread).
+//
+// Reference semantics: transformer/MFT/multiTransformer.py:22-34 (scaled dot-product attention) under autograd.
+#pragma once
+#include "attn.h"
+
+#define MMT_FUSED_NW 16
+#define MMT_FUSED_THREADS (MMT_FUSED_NW * 64)
+#define MMT_FUSED_PATCH_LD 40                               // bf16 per patch row: 32 keys + 8 pad (80-byte rows: conflict-free b128 reads)
+#define MMT_FUSED_PART_LD 68                                // floats per partial register row: 64 lanes + 4 pad
+#define MMT_FUSED_REGION_BYTES 2560                         // max(32 * 40 * 2, 8 * 68 * 4)
+#define MMT_FUSED_STAGE_PIECES 400                          // 2 * 64 (R tiles) + 2 * 128 (T tiles) + 2 * 8 (row constants)
+#define MMT_FUSED_LDS_BYTES (2 * MMT_FUSED_STAGE_PIECES * 16 + MMT_FUSED_NW * 4096 + MMT_FUSED_NW * 2 * MMT_FUSED_REGION_BYTES)     // 160,256 of 163,840
+
+__host__ inline bool attn_bwd_fused_ok(int DKP, int nt) { return DKP == 16 && nt > 8 && nt <= MMT_FUSED_NW; }
+
+template <bool DROP>
+__global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
+        const bf16* __restrict__ Qr, const bf16* __restrict__ Qt, const bf16* __restrict__ Kr, const bf16* __restrict__ Kt,
+        const bf16* __restrict__ Vr, const bf16* __restrict__ dOr, const bf16* __restrict__ dOt,
+        const float* __restrict__ lse, const float* __restrict__ delta, const float* __restrict__ rowmask, float scale,
+        bf16* __restrict__ dqkv, int lddkv,     // row-major [M][lddkv]: dQ at column 0, dK at HD, dV at 2*HD
+        bf16* __restrict__ dqkvT, int MP,       // T layout  [3*HD rows][MP]
+        int h, int T, int nt, DropCfg drop) {
+    constexpr int DKP = 16, PR = 64, PT = 128, PC = 8, TOTAL = MMT_FUSED_STAGE_PIECES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* const stage0 = reinterpret_cast<bf16*>(smem);                                 // [2][TOTAL * 8] bf16
+    char* const ktl0 = smem + 2 * TOTAL * 16;                                           // [NW][2048]: own K^T tile (T layout)
+    char* const kvl0 = ktl0 + MMT_FUSED_NW * 2048;                                      // [NW][2][1024]: own K and V tiles (R layout)
+    char* const reg0 = kvl0 + MMT_FUSED_NW * 2048;                                      // [NW][2][REGION]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int kt = wave;
+    const bool live = kt < nt;                          // idle waves stage, synchronise and take their share of the dQ reduction
+    const int bh = blockIdx.x, b = bh / h, head = bh - b * h;
+    const int Tp = nt * 32, HD = h * DKP;
+    const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
+    const DropCfg dc = DROP ? drop_substream(drop, (uint32_t)bh) : drop;       // per-(batch,head) stream
+
+    // ---- staging ring: thread p < 400 moves piece p of every tile (segments: Q R, dO R, Q T, dO T, L, delta)
+    const bf16* ssrc; int sstride; const bool son = tid < TOTAL;
+    {
+        const bf16* base[6] = {Qr + offR, dOr + offR, Qt + offT, dOt + offT,
+                               reinterpret_cast<const bf16*>(lse + (size_t)bh * Tp), reinterpret_cast<const bf16*>(delta + (size_t)bh * Tp)};
+        const int pieces[6] = {PR, PR, PT, PT, PC, PC}, strides[6] = {32 * DKP, 32 * DKP, 1024, 1024, 64, 64};
+        int acc = 0; ssrc = base[0]; sstride = 0;
+#pragma unroll
+        for (int sg = 0; sg < 6; ++sg) {
+            if (tid >= acc && tid < acc + pieces[sg]) { ssrc = base[sg] + (size_t)(tid - acc) * 8; sstride = strides[sg]; }
+            acc += pieces[sg];
+        }
+    }
+    bf16x8 sreg;
+    auto stage_load = [&](int tile) { if (son) sreg = *reinterpret_cast<const bf16x8*>(ssrc + (size_t)tile * sstride); };
+    auto stage_store = [&](int buf) { if (son) *reinterpret_cast<bf16x8*>(stage0 + (size_t)buf * TOTAL * 8 + tid * 8) = sreg; };
+    stage_load(0);
+
+    // ---- per-wave constants
+    char* const myreg = reg0 + wave * 2 * MMT_FUSED_REGION_BYTES;
+    char* const mykv = kvl0 + wave * 2048 + lane * 16;
+    {
+        const int ktc = live ? kt : 0;
+        const size_t off = ((size_t)(ktc * (DKP / 8) + hh) * 32 + r) * 8;
+        *reinterpret_cast<bf16x8*>(mykv) = *reinterpret_cast<const bf16x8*>(Kr + offR + off);
+        *reinterpret_cast<bf16x8*>(mykv + 1024) = *reinterpret_cast<const bf16x8*>(Vr + offR + off);
+        // own K^T tile -> LDS (128 pieces, two per lane), the A operand of the dQ product
+        const bf16* ksrc = Kt + offT + (size_t)ktc * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<bf16x8*>(ktl0 + wave * 2048 + (lane + 64 * i) * 16) = *reinterpret_cast<const bf16x8*>(ksrc + (lane + 64 * i) * 8);
+        if (!live) {                                    // an idle wave's partials are zero forever
+#pragma unroll
+            for (int par = 0; par < 2; ++par)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) reinterpret_cast<float*>(myreg + par * MMT_FUSED_REGION_BYTES)[j * MMT_FUSED_PART_LD + lane] = 0.f;
+        }
+    }
+    f32x16 acc;                                         // rows 0..15: dV^T, rows 16..31: dK^T (see attn_bwd_dkv_kernel)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    const int rq = r ^ 16;
+    const bool key_tail = live && (kt == nt - 1) && (T & 31);
+    const uint32_t kcol = (uint32_t)(kt * 32 + r);
+    // dropout lane constants (attn_bwd_dkv_kernel)
+    const uint32_t hC = ((uint32_t)Tp >> 1) * MMT_DROP_C1;
+    const uint32_t par = kcol & 1u;
+    const uint32_t xk = DROP ? drop_lin(dc.s0, (kcol >> 1)) + (uint32_t)(4 * hh + (int)par) * hC : 0u;
+    const uint32_t hmask = par ? 0xFFFF0000u : 0x0000FFFFu, hthr = par ? (dc.thr16 << 16) : dc.thr16;
+    // dQ reduction: this lane's output of a tile.  Lanes 0..31: T layout, feature e = wave, query q = lane; lanes 32..63: row-major,
+    // query 2*wave + (lane>>4 & 1), feature lane & 15.  Partial word of (e, q): register (e&3) + 4*(e>>3), lane q + 32*((e>>2)&1).
+    const int oe = hh ? (lane & 15) : wave, oq = hh ? (2 * wave + ((lane >> 4) & 1)) : r;
+    const int poff = ((oe & 3) + 4 * (oe >> 3)) * MMT_FUSED_PART_LD + oq + 32 * ((oe >> 2) & 1);
+    const float* const pbase = reinterpret_cast<const float*>(reg0) + poff;
+    const size_t m0 = (size_t)b * T;
+
+    stage_store(0);
+    __syncthreads();
+
+    auto body = [&](auto tail_tag, int qt) {
+        constexpr bool QTAIL = decltype(tail_tag)::value;
+        const bool more = qt + 1 < nt;
+        if (more) stage_load(qt + 1);
+        // this lane's output row of the tile, and its mask value, fetched a tile-time before use
+        const int oqt = qt * 32 + oq;
+        const bool orow = !QTAIL || oqt < T;
+        const size_t om = m0 + (orow ? oqt : 0);
+        const float rm = rowmask ? rowmask[om] : 1.f;
+        char* const region = myreg + (qt & 1) * MMT_FUSED_REGION_BYTES;
+        if (live) {
+            const bf16* sq = stage0 + (size_t)(qt & 1) * TOTAL * 8;
+            const bf16* sdo = sq + PR * 8;
+            const bf16* sqt = sq + 2 * PR * 8;
+            const bf16* sdt = sqt + PT * 8;
+            const float* sl = reinterpret_cast<const float*>(sdt + PT * 8);
+            const float* sd = sl + 32;
+            f32x16 s, dp;               // row constants (4 consecutive queries per register group) as the accumulators
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl + 8 * g + 4 * hh);
+                f32x4 d4 = {0.f, 0.f, 0.f, 0.f};                               // DROP: -delta enters after the mask
+                if (!DROP) d4 = *reinterpret_cast<const f32x4*>(sd + 8 * g + 4 * hh);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { s[4 * g + i] = l4[i]; dp[4 * g + i] = d4[i]; }  // both stored negated
+            }
+            const int o8 = (hh * 32 + r) * 8;
+            s = mfma32(*reinterpret_cast<const bf16x8*>(sq + o8), *reinterpret_cast<const bf16x8*>(mykv), s);
+            dp = mfma32(*reinterpret_cast<const bf16x8*>(sdo + o8), *reinterpret_cast<const bf16x8*>(mykv + 1024), dp);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float pv = fast_exp2(s[j]);
+                if (QTAIL) pv = (qt * 32 + acc32_row(j, hh) < T) ? pv : 0.f;  // queries >= T do not exist
+                s[j] = pv;
+            }
+            if (key_tail) {                             // wave-uniform, loop-invariant: only the last key tile's wave pays
+                const float kmul = ((int)kcol < T) ? 1.f : 0.f;        // keys >= T do not exist
+#pragma unroll
+                for (int j = 0; j < 16; ++j) s[j] *= kmul;
+            }
+            if (DROP) {
+                const uint32_t xt = xk + (uint32_t)qt * (32u * hC);
+                uint32_t mine[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) mine[k] = drop_fin(xt + (uint32_t)(((2 * k) & 3) + 8 * (k >> 1)) * hC, dc.s1);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + 8 * g + 4 * hh);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int j = 4 * g + i;
+                        const uint32_t w = (i & 1) ? quad_bcast<0xF5>(mine[j >> 1]) : quad_bcast<0xA0>(mine[j >> 1]);
+                        const float ms = ((w & hmask) >= hthr) ? dc.scale : 0.f;
+                        dp[j] = s[j] * fmaf(dp[j], ms, d4[i]);
+                        s[j] *= ms;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) dp[j] *= s[j];
+            }
+            // dV^T / dK^T, and dS into the patch on the way.  This lane's key column goes where the K^T tile's k-order wants it (bits 2
+            // and 3 of the key swapped); recomputed per tile from an opaque copy of the lane id — as a loop invariant it is the
+            // register that spills, and a scratch reload's vmcnt(0) would also wait for the staging prefetch.
+            int rr = r;
+            asm volatile("" : "+v"(rr));
+            const int pcol = (rr & 19) | ((rr & 4) << 1) | ((rr & 8) >> 1);
+            bf16* const patch = reinterpret_cast<bf16*>(region);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int o8b = ((s2 * 2 + hh) * 32 + r) * 8;
+                const bf16x8 pds = pack8(dp, s2);
+                acc = mfma32(*reinterpret_cast<const bf16x8*>(sdt + o8b), pack8(s, s2), acc);
+                acc = mfma32(*reinterpret_cast<const bf16x8*>(sqt + ((s2 * 2 + hh) * 32 + rq) * 8), pds, acc);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)             // register 8*s2 + j holds query row acc32_row(8*s2 + j, hh) of this lane's key
+                    patch[acc32_row(8 * s2 + j, hh) * MMT_FUSED_PATCH_LD + pcol] = pds[j];
+            }
+            // dQ^T share of this key tile: K^T (features x keys) times dS^T (keys x queries)
+            f32x16 dqp;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dqp[j] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(patch + r * MMT_FUSED_PATCH_LD + 16 * s2 + 8 * hh);
+                const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(ktl0 + wave * 2048 + ((s2 * 2 + hh) * 32 + r) * 16);
+                dqp = mfma32(afrag, bfrag, dqp);
+            }
+            float* const part = reinterpret_cast<float*>(region);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[j * MMT_FUSED_PART_LD + lane] = dqp[j];        // feature rows >= 16 are padding
+        }
+        if (more) stage_store((qt + 1) & 1);
+        __syncthreads();
+        // ---- all 16 partials of tile qt are in LDS: fixed-order sum, scale, mask, store
+        {
+            const float* pp = pbase + (qt & 1) * (MMT_FUSED_REGION_BYTES / 4);
+            float v = pp[0];
+#pragma unroll
+            for (int w2 = 1; w2 < MMT_FUSED_NW; ++w2) v += pp[w2 * (2 * MMT_FUSED_REGION_BYTES / 4)];
+            v *= (rm == 0.0f) ? 0.f : scale;            // blanked query rows pass no gradient to Q
+            bf16* const dst = hh ? (dqkv + om * lddkv + head * DKP + oe) : (dqkvT + (size_t)(head * DKP + oe) * MP + om);
+            if (orow) *dst = (bf16)v;
+        }
+    };
+    for (int qt = 0; qt < nt - 1; ++qt) body(std::false_type{}, qt);
+    if (T & 31) body(std::true_type{}, nt - 1); else body(std::false_type{}, nt - 1);
+    if (!live) return;
+    // dK = ln2 * acc rows 16.. (scores are in the log2 domain), dV = acc rows 0..15; column key = r
+    const float LN2 = 0.6931471805599453f;
+    const int t = kt * 32 + r;
+    if (t < T) {
+        const size_t m = m0 + t;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            bf16x4 kv, vv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { kv[j] = (bf16)(acc[8 + 4 * g + j] * LN2); vv[j] = (bf16)acc[4 * g + j]; }
+            const int e0 = head * DKP + 8 * g + 4 * hh;
+            *reinterpret_cast<bf16x4*>(dqkv + m * lddkv + HD + e0) = kv;
+            *reinterpret_cast<bf16x4*>(dqkv + m * lddkv + 2 * HD + e0) = vv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dqkvT[(size_t)(HD + e0 + j) * MP + m] = kv[j];
+                dqkvT[(size_t)(2 * HD + e0 + j) * MP + m] = vv[j];
+            }
+        }
+    }
+}

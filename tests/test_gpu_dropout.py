@@ -45,7 +45,8 @@ def _masks(dev, p, seed, n_layers, B, T, d, h, f):
 
 
 @pytest.mark.parametrize("d,h,n,B,T,lengths,p", [(128, 8, 2, 3, 50, [50, 31, 6], 0.1), (40, 4, 2, 2, 33, [33, 9], 0.25),
-                                                 (256, 8, 1, 2, 70, [70, 64], 0.1)])
+                                                 (256, 8, 1, 2, 70, [70, 64], 0.1),
+                                                 (128, 8, 1, 2, 300, [300, 170], 0.1)])       # one-kernel attention backward
 def test_train_mode_replay_with_kernel_masks(dev, d, h, n, B, T, lengths, p):
     MT = mta().multiTransformer
     F = mta().functional

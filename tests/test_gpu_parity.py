@@ -138,7 +138,9 @@ def test_linear(dev, M, K, N, act, rs):
 # ------------------------------------------------------------------------------------------ attention core
 @pytest.mark.parametrize("B,T,d,h,lengths", [
     (2, 50, 128, 8, [50, 20]), (3, 33, 40, 4, [33, 32, 1]), (2, 64, 256, 8, [64, 7]), (1, 1, 16, 1, [1]),
-    (2, 300, 40, 4, [300, 41]), (1, 500, 128, 8, [350]), (1, 257, 256, 8, [257])])
+    (2, 300, 40, 4, [300, 41]), (1, 500, 128, 8, [350]), (1, 257, 256, 8, [257]),
+    # one-kernel backward (attn_bwd_fused.h: d_k <= 16, 9..16 key tiles): 9 tiles, a full last tile, 16 tiles with a ragged tail
+    (2, 257, 128, 8, [257, 256]), (1, 512, 64, 4, [512]), (2, 481, 128, 8, [481, 3])])
 def test_sdpa(dev, B, T, d, h, lengths):
     tag = "sdpa%d_%d_%d" % (T, d, h)
     q, k, v, g = (R.gen_normal(tag + n, (B, T, d), 7) for n in "qkvg")
