@@ -12,7 +12,8 @@
 //   * the fp32 partial (8 registers for d_k <= 16) overwrites the patch, and after the tile's barrier all 16 waves sum the 16
 //     partials in a fixed order (bit-reproducible, no atomics), apply 1/sqrt(d_k) and the query-row mask and store both layouts of
 //     dQ — each wave 32 outputs per layout, coalesced.  Patch/partial regions are double-buffered by tile parity, so one barrier
-//     per tile orders everything.
+//     per tile orders everything;
+//   * the score products of tile t+1 are issued before the barrier that closes tile t (three-deep staging ring), see "Pipeline".
 // Registers: 16 waves per CU means 128 VGPRs per wave; the kernel is written to fit (the own tile's K, V and K^T fragments live in
 // LDS instead of registers, the staging ring needs one 16-byte piece per thread).
 //
@@ -26,7 +27,7 @@
 #define MMT_FUSED_PART_LD 68                                // floats per partial register row: 64 lanes + 4 pad
 #define MMT_FUSED_REGION_BYTES 2560                         // max(32 * 40 * 2, 8 * 68 * 4)
 #define MMT_FUSED_STAGE_PIECES 400                          // 2 * 64 (R tiles) + 2 * 128 (T tiles) + 2 * 8 (row constants)
-#define MMT_FUSED_LDS_BYTES (2 * MMT_FUSED_STAGE_PIECES * 16 + MMT_FUSED_NW * 4096 + MMT_FUSED_NW * 2 * MMT_FUSED_REGION_BYTES)     // 160,256 of 163,840
+#define MMT_FUSED_LDS_BYTES (3 * MMT_FUSED_STAGE_PIECES * 16 + MMT_FUSED_NW * 3072 + MMT_FUSED_NW * 2 * MMT_FUSED_REGION_BYTES)     // 150,272 of 163,840
 
 __host__ inline bool attn_bwd_fused_ok(int DKP, int nt) { return DKP == 16 && nt > 8 && nt <= MMT_FUSED_NW; }
 
@@ -40,9 +41,9 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
         int h, int T, int nt, DropCfg drop) {
     constexpr int DKP = 16, PR = 64, PT = 128, PC = 8, TOTAL = MMT_FUSED_STAGE_PIECES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* const stage0 = reinterpret_cast<bf16*>(smem);                                 // [2][TOTAL * 8] bf16
-    char* const ktl0 = smem + 2 * TOTAL * 16;                                           // [NW][2048]: own K^T tile (T layout)
-    char* const kvl0 = ktl0 + MMT_FUSED_NW * 2048;                                      // [NW][2][1024]: own K and V tiles (R layout)
+    bf16* const stage0 = reinterpret_cast<bf16*>(smem);                                 // [3][TOTAL * 8] bf16: ring of query tiles
+    char* const ktl0 = smem + 3 * TOTAL * 16;                                           // [NW][1024]: own K^T tile, its 16 real rows
+    char* const kvl0 = ktl0 + MMT_FUSED_NW * 1024;                                      // [NW][2][1024]: own K and V tiles (R layout)
     char* const reg0 = kvl0 + MMT_FUSED_NW * 2048;                                      // [NW][2][REGION]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -68,7 +69,11 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
     }
     bf16x8 sreg;
     auto stage_load = [&](int tile) { if (son) sreg = *reinterpret_cast<const bf16x8*>(ssrc + (size_t)tile * sstride); };
-    auto stage_store = [&](int buf) { if (son) *reinterpret_cast<bf16x8*>(stage0 + (size_t)buf * TOTAL * 8 + tid * 8) = sreg; };
+    auto stage_store = [&](int buf) {
+        int to = tid;
+        asm volatile("" : "+v"(to));
+        if (son) *reinterpret_cast<bf16x8*>(stage0 + (size_t)buf * TOTAL * 8 + to * 8) = sreg;
+    };
     stage_load(0);
 
     // ---- per-wave constants
@@ -79,11 +84,9 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
         const size_t off = ((size_t)(ktc * (DKP / 8) + hh) * 32 + r) * 8;
         *reinterpret_cast<bf16x8*>(mykv) = *reinterpret_cast<const bf16x8*>(Kr + offR + off);
         *reinterpret_cast<bf16x8*>(mykv + 1024) = *reinterpret_cast<const bf16x8*>(Vr + offR + off);
-        // own K^T tile -> LDS (128 pieces, two per lane), the A operand of the dQ product
+        // own K^T tile -> LDS, the A operand of the dQ product: only feature rows < 16 of each (s, hh) block are real (one piece per lane)
         const bf16* ksrc = Kt + offT + (size_t)ktc * 1024;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<bf16x8*>(ktl0 + wave * 2048 + (lane + 64 * i) * 16) = *reinterpret_cast<const bf16x8*>(ksrc + (lane + 64 * i) * 8);
+        *reinterpret_cast<bf16x8*>(ktl0 + wave * 1024 + lane * 16) = *reinterpret_cast<const bf16x8*>(ksrc + ((lane >> 4) * 32 + (lane & 15)) * 8);
         if (!live) {                                    // an idle wave's partials are zero forever
 #pragma unroll
             for (int par = 0; par < 2; ++par)
@@ -94,7 +97,6 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
     f32x16 acc;                                         // rows 0..15: dV^T, rows 16..31: dK^T (see attn_bwd_dkv_kernel)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    const int rq = r ^ 16;
     const bool key_tail = live && (kt == nt - 1) && (T & 31);
     const uint32_t kcol = (uint32_t)(kt * 32 + r);
     // dropout lane constants (attn_bwd_dkv_kernel)
@@ -107,40 +109,62 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
     const int oe = hh ? (lane & 15) : wave, oq = hh ? (2 * wave + ((lane >> 4) & 1)) : r;
     const int poff = ((oe & 3) + 4 * (oe >> 3)) * MMT_FUSED_PART_LD + oq + 32 * ((oe >> 2) & 1);
     const float* const pbase = reinterpret_cast<const float*>(reg0) + poff;
-    const size_t m0 = (size_t)b * T;
+    // its destination is linear in the tile index: element offsets from dqkv (row-major half) or dqkvT, and the step per tile
+    const uint32_t m0 = (uint32_t)b * (uint32_t)T;
+    uint32_t doff = hh ? ((m0 + oq) * (uint32_t)lddkv + head * DKP + oe) : ((uint32_t)(head * DKP + oe) * (uint32_t)MP + m0 + oq);
+    uint32_t rmoff = m0 + oq;
 
+    // Pipeline.  The staged ring is three tiles deep: tile t+2 is fetched during tile t, so tile t+1 is already visible while tile t
+    // is processed, and each wave issues the score products S(t+1), dP(t+1) BEFORE the barrier that closes tile t.  After a barrier
+    // every wave therefore starts with VALU work on finished MFMA results (and the dQ reduction of the tile just closed) instead of
+    // all 16 waves queueing on LDS reads and the MFMA pipe at once — with one workgroup per CU nothing else would fill that bubble.
     stage_store(0);
+    if (nt > 1) { stage_load(1); stage_store(1); }
     __syncthreads();
 
-    auto body = [&](auto tail_tag, int qt) {
+    f32x16 s, dp;                       // S' - L and dP (- delta) of the current tile, produced one tile ahead
+    // LDS addresses derived from the lane id are recomputed where they are used, from an opaque copy of it: kept as loop invariants
+    // they are what spills at 128 VGPRs, and a scratch reload's vmcnt(0) would also wait for the staging prefetch.
+    auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
+    auto scores = [&](int buf) {        // row constants (4 consecutive queries per register group) are the accumulator init
+        const int lo = opaque(lane), r = lo & 31, hh = lo >> 5;
+        char* const mykv = kvl0 + wave * 2048 + lo * 16;
+        const bf16* sq = stage0 + (size_t)buf * TOTAL * 8;
+        const bf16* sdo = sq + PR * 8;
+        const float* sl = reinterpret_cast<const float*>(sq + (2 * PR + 2 * PT) * 8);
+        const float* sd = sl + 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl + 8 * g + 4 * hh);
+            f32x4 d4 = {0.f, 0.f, 0.f, 0.f};                                   // DROP: -delta enters after the mask
+            if (!DROP) d4 = *reinterpret_cast<const f32x4*>(sd + 8 * g + 4 * hh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s[4 * g + i] = l4[i]; dp[4 * g + i] = d4[i]; }      // both stored negated
+        }
+        const int o8 = (hh * 32 + r) * 8;
+        s = mfma32(*reinterpret_cast<const bf16x8*>(sq + o8), *reinterpret_cast<const bf16x8*>(mykv), s);
+        dp = mfma32(*reinterpret_cast<const bf16x8*>(sdo + o8), *reinterpret_cast<const bf16x8*>(mykv + 1024), dp);
+    };
+    if (live) scores(0);
+    else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s[j] = 0.f; dp[j] = 0.f; }
+    }
+    int cur = 0, nxt = 1, nn = 2;       // ring slots of tiles qt, qt+1, qt+2
+
+    auto body = [&](auto tail_tag, auto next_tag, int qt) {
         constexpr bool QTAIL = decltype(tail_tag)::value;
-        const bool more = qt + 1 < nt;
-        if (more) stage_load(qt + 1);
-        // this lane's output row of the tile, and its mask value, fetched a tile-time before use
-        const int oqt = qt * 32 + oq;
-        const bool orow = !QTAIL || oqt < T;
-        const size_t om = m0 + (orow ? oqt : 0);
-        const float rm = rowmask ? rowmask[om] : 1.f;
+        constexpr bool NEXT = decltype(next_tag)::value;                        // a tile qt+1 exists
+        const bool more = qt + 2 < nt;
+        if (more) stage_load(qt + 2);
+        // the mask value of this lane's output row, fetched a tile-time before use
+        const bool orow = !QTAIL || (qt * 32 + oq) < T;
+        float rm = rowmask ? rowmask[orow ? rmoff : m0] : 1.f;
         char* const region = myreg + (qt & 1) * MMT_FUSED_REGION_BYTES;
         if (live) {
-            const bf16* sq = stage0 + (size_t)(qt & 1) * TOTAL * 8;
-            const bf16* sdo = sq + PR * 8;
-            const bf16* sqt = sq + 2 * PR * 8;
+            const bf16* sqt = stage0 + (size_t)cur * TOTAL * 8 + 2 * PR * 8;
             const bf16* sdt = sqt + PT * 8;
-            const float* sl = reinterpret_cast<const float*>(sdt + PT * 8);
-            const float* sd = sl + 32;
-            f32x16 s, dp;               // row constants (4 consecutive queries per register group) as the accumulators
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl + 8 * g + 4 * hh);
-                f32x4 d4 = {0.f, 0.f, 0.f, 0.f};                               // DROP: -delta enters after the mask
-                if (!DROP) d4 = *reinterpret_cast<const f32x4*>(sd + 8 * g + 4 * hh);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { s[4 * g + i] = l4[i]; dp[4 * g + i] = d4[i]; }  // both stored negated
-            }
-            const int o8 = (hh * 32 + r) * 8;
-            s = mfma32(*reinterpret_cast<const bf16x8*>(sq + o8), *reinterpret_cast<const bf16x8*>(mykv), s);
-            dp = mfma32(*reinterpret_cast<const bf16x8*>(sdo + o8), *reinterpret_cast<const bf16x8*>(mykv + 1024), dp);
+            const float* sd = reinterpret_cast<const float*>(sdt + PT * 8) + 32;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 float pv = fast_exp2(s[j]);
@@ -174,11 +198,9 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
                 for (int j = 0; j < 16; ++j) dp[j] *= s[j];
             }
             // dV^T / dK^T, and dS into the patch on the way.  This lane's key column goes where the K^T tile's k-order wants it (bits 2
-            // and 3 of the key swapped); recomputed per tile from an opaque copy of the lane id — as a loop invariant it is the
-            // register that spills, and a scratch reload's vmcnt(0) would also wait for the staging prefetch.
-            int rr = r;
-            asm volatile("" : "+v"(rr));
-            const int pcol = (rr & 19) | ((rr & 4) << 1) | ((rr & 8) >> 1);
+            // and 3 of the key swapped).
+            const int lo = opaque(lane), r = lo & 31, hh = lo >> 5, rq = r ^ 16;
+            const int pcol = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);
             bf16* const patch = reinterpret_cast<bf16*>(region);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -190,41 +212,50 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
                 for (int j = 0; j < 8; ++j)             // register 8*s2 + j holds query row acc32_row(8*s2 + j, hh) of this lane's key
                     patch[acc32_row(8 * s2 + j, hh) * MMT_FUSED_PATCH_LD + pcol] = pds[j];
             }
-            // dQ^T share of this key tile: K^T (features x keys) times dS^T (keys x queries)
+            // dQ^T share of this key tile: K^T (features x keys) times dS^T (keys x queries); lanes r >= 16 would produce the padding
+            // feature rows, which nobody reads, so they fetch the same K^T rows as lanes r - 16
             f32x16 dqp;
 #pragma unroll
             for (int j = 0; j < 16; ++j) dqp[j] = 0.f;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(patch + r * MMT_FUSED_PATCH_LD + 16 * s2 + 8 * hh);
-                const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(ktl0 + wave * 2048 + ((s2 * 2 + hh) * 32 + r) * 16);
+                const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(ktl0 + wave * 1024 + ((s2 * 2 + hh) * 16 + (r & 15)) * 16);
                 dqp = mfma32(afrag, bfrag, dqp);
             }
             float* const part = reinterpret_cast<float*>(region);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) part[j * MMT_FUSED_PART_LD + lane] = dqp[j];        // feature rows >= 16 are padding
+            for (int j = 0; j < 8; ++j) part[j * MMT_FUSED_PART_LD + lo] = dqp[j];          // feature rows >= 16 are padding
+            if (NEXT) scores(nxt);                      // tile qt+1 has been visible since the previous barrier
         }
-        if (more) stage_store((qt + 1) & 1);
+        if (more) stage_store(nn);
         __syncthreads();
-        // ---- all 16 partials of tile qt are in LDS: fixed-order sum, scale, mask, store
+        // ---- all 16 partials of tile qt are in LDS: fixed-order sum (as 8 packed pairs), scale, mask, store
         {
+            asm volatile("" : "+v"(rm));                // first use of the mask value AFTER the barrier: no wait on its load before
             const float* pp = pbase + (qt & 1) * (MMT_FUSED_REGION_BYTES / 4);
-            float v = pp[0];
+            f32x2 v2 = {pp[0], pp[2 * MMT_FUSED_REGION_BYTES / 4]};
 #pragma unroll
-            for (int w2 = 1; w2 < MMT_FUSED_NW; ++w2) v += pp[w2 * (2 * MMT_FUSED_REGION_BYTES / 4)];
-            v *= (rm == 0.0f) ? 0.f : scale;            // blanked query rows pass no gradient to Q
-            bf16* const dst = hh ? (dqkv + om * lddkv + head * DKP + oe) : (dqkvT + (size_t)(head * DKP + oe) * MP + om);
-            if (orow) *dst = (bf16)v;
+            for (int w2 = 2; w2 < MMT_FUSED_NW; w2 += 2) {
+                const f32x2 t = {pp[w2 * (2 * MMT_FUSED_REGION_BYTES / 4)], pp[(w2 + 1) * (2 * MMT_FUSED_REGION_BYTES / 4)]};
+                v2 += t;
+            }
+            const float v = (v2[0] + v2[1]) * ((rm == 0.0f) ? 0.f : scale);     // blanked query rows pass no gradient to Q
+            bf16* const dbase = (opaque(lane) >> 5) ? dqkv : dqkvT;
+            if (orow) dbase[doff] = (bf16)v;
+            doff += (opaque(lane) >> 5) ? 32u * (uint32_t)lddkv : 32u;
+            rmoff += 32u;
         }
+        const int t3 = cur; cur = nxt; nxt = nn; nn = t3;
     };
-    for (int qt = 0; qt < nt - 1; ++qt) body(std::false_type{}, qt);
-    if (T & 31) body(std::true_type{}, nt - 1); else body(std::false_type{}, nt - 1);
+    for (int qt = 0; qt < nt - 1; ++qt) body(std::false_type{}, std::true_type{}, qt);
+    if (T & 31) body(std::true_type{}, std::false_type{}, nt - 1); else body(std::false_type{}, std::false_type{}, nt - 1);
     if (!live) return;
     // dK = ln2 * acc rows 16.. (scores are in the log2 domain), dV = acc rows 0..15; column key = r
     const float LN2 = 0.6931471805599453f;
     const int t = kt * 32 + r;
     if (t < T) {
-        const size_t m = m0 + t;
+        const size_t m = (size_t)m0 + t;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             bf16x4 kv, vv;
