@@ -35,7 +35,7 @@ static int fail(int code, const char* fmt, ...) {
 // dominant kernel's average duration on the stream the kernels really run on.
 enum Site { S_PREP = 0, S_LN1_QKV, S_ATTN_FWD, S_OUTPROJ, S_LN2_FFN1, S_FFN2, S_LN_FWD, S_LN_BWD, S_BWD_FFN2, S_BWD_FFN1_LN2,
             S_BWD_OUTPROJ, S_ATTN_BWD, S_ATTN_BWD_DQ, S_BWD_QKV_LN1, S_WGRAD, S_FINALIZE, S_OTHER,
-            S_LINEAR_FWD, S_LINEAR_BWD_DX, S_LINEAR_WGRAD, S_LSTM_FWD, S_LSTM_BWD, S_MEM_FWD, S_MEM_BWD, S_CONV_FWD, S_CONV_BWD, S_CHAIN4_FWD, S_COUNT };
+            S_LINEAR_FWD, S_LINEAR_BWD_DX, S_LINEAR_WGRAD, S_LSTM_FWD, S_LSTM_BWD, S_MEM_FWD, S_MEM_BWD, S_CONV_FWD, S_CONV_BWD, S_CHAIN4_FWD, S_ATTN_BWD_FUSED, S_COUNT };
 static const char* const g_site_names[S_COUNT] = {
     "encoder_prep_kernel", "rowgemm<FRAG,LN>:ln1+qkv", "attn_fwd_kernel", "chain:outproj+res>ln2+ffn1>ffn2+res",
     "rowgemm<PLAIN,LN>:ln2+ffn1+relu", "rowgemm<PLAIN>:ffn2+res", "layernorm_fwd_kernel", "layernorm_bwd_kernel",
@@ -43,7 +43,7 @@ static const char* const g_site_names[S_COUNT] = {
     "attn_bwd_dq_kernel", "rowgemm<LNBWD>:bwd_qkv+ln1", "wgrad_kernel", "finalize_kernels", "other",
     "rowgemm<PLAIN>:linear_fwd", "rowgemm<PLAIN>:linear_bwd_dx", "wgrad_kernel:linear", "lstm_scan_fwd_kernel", "lstm_scan_bwd_kernel",
     "mfn_mem_scan_fwd_kernel", "mfn_mem_scan_bwd_kernel", "convpool_fwd_kernel", "convpool_bwd_kernel",
-    "chain:outproj+res>ln2+ffn1>ffn2+res>ln1+qkv(next)"};
+    "chain:outproj+res>ln2+ffn1>ffn2+res>ln1+qkv(next)", "attn_bwd_fused16_kernel"};
 struct ProfRec { int site; hipEvent_t a, b; };
 static bool g_prof = false;
 static ProfRec* g_recs = nullptr;
@@ -267,7 +267,7 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             configured = true;
         }
-        ProfScope prof(S_ATTN_BWD, st);
+        ProfScope prof(S_ATTN_BWD_FUSED, st);
 #define MMT_FUSED(dr) hipLaunchKernelGGL((attn_bwd_fused16_kernel<dr>), dim3(D.B * D.h), dim3(MMT_FUSED_THREADS), MMT_FUSED_LDS_BYTES, st, \
                                           QR, QT, KR, KT_, VR, dOR, dOT, lse, delta, rowmask, scale, dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, drop)
         if (drop.thr16) MMT_FUSED(true); else MMT_FUSED(false);
@@ -1070,6 +1070,29 @@ __global__ void dropout_mask_kernel(DropCfg c, uint64_t n, uint32_t attn_Tp, uin
         keep[i] = (((idx & 1) ? (w >> 16) : (w & 0xFFFFu)) >= c.thr16) ? 1 : 0;
     }
 }
+// Test hook: leave a chosen bit pattern in every LDS word (and a spread of VGPRs) of every CU.  A kernel whose result depends on LDS
+// it never wrote (what a freshly powered GPU hands it: the first process on a box) then produces a different answer after this call.
+__global__ __launch_bounds__(1024) void poison_lds_kernel(uint32_t pattern, int words, uint32_t* sink) {
+    extern __shared__ uint32_t poison_smem[];
+    for (int i = threadIdx.x; i < words; i += blockDim.x) poison_smem[i] = pattern;
+    __syncthreads();
+    // keep the stores alive and hold the CU for a moment so that the grid spreads over all CUs
+    uint32_t acc = 0;
+    for (int i = threadIdx.x; i < words; i += blockDim.x * 7) acc ^= poison_smem[i];
+    if (acc == 0x12345u) sink[0] = acc;
+}
+extern "C" int mmt_debug_poison_lds(uint32_t pattern, void* sink4, mmt_stream_t stream) {
+    if (!sink4) return fail(MMT_EINVAL, "null pointer argument");
+    static bool configured = false;
+    if (!configured) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(1024), 160 * 1024, static_cast<hipStream_t>(stream), pattern, 160 * 256, static_cast<uint32_t*>(sink4));
+    LAUNCH_CHECK("poison_lds_kernel");
+    return MMT_OK;
+}
+
 extern "C" int mmt_debug_dropout_mask(float p, uint64_t seed, uint32_t stream_id, uint64_t n, uint32_t attn_Tp, uint8_t* keep,
                                       float* scale_out, mmt_stream_t stream) {
     if (!keep) return fail(MMT_EINVAL, "null pointer argument");

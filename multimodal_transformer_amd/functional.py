@@ -408,6 +408,13 @@ def mfn_mem_scan(apre, chat, Wm, W2, b2, dropout_p=0.0, seed=0):
     return _MfnMemScanFn.apply(apre, chat, Wm, W2, b2, float(dropout_p), int(seed))
 
 
+def poison_lds(device, pattern=0x7FC00000):
+    """Test hook: leave `pattern` in every LDS word of every CU (see include/mmt_hip.h)."""
+    lib = _lib.load()
+    sink = torch.zeros(1, dtype=torch.int32, device=device)
+    _lib.check(lib.mmt_debug_poison_lds(int(pattern), _lib.ptr(sink), _lib.stream_ptr()))
+
+
 def dropout_mask(p, seed, stream_id, n, device, attn_Tp=0):
     """Test hook: (keep mask as a bool tensor of n entries, scale of kept values) of one dropout stream."""
     import ctypes

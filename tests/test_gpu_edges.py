@@ -160,3 +160,27 @@ def test_default_model_under_hipgraph_replay(dev):
         torch.cuda.synchronize()
         assert torch.equal(y_static, y_ref)
         assert torch.equal(params[0].grad, g_ref)
+
+
+@pytest.mark.parametrize("d,h,B,T,p", [(128, 8, 3, 300, 0.1), (256, 8, 2, 70, 0.1), (40, 4, 2, 33, 0.0)])
+def test_results_do_not_depend_on_unwritten_lds(dev, d, h, B, T, p):
+    """a kernel may only read LDS it wrote: fill every CU's LDS with NaN bit patterns between two identical seeded runs
+    (what the first process on a freshly powered GPU can find there) and require bit-identical outputs and gradients"""
+    from multimodal_transformer_amd import functional as F
+    enc, _ = _encoder(d, h, 2, dev)
+    flat = torch.cat([q.reshape(-1) for q in enc.flat_parameters()]).detach()
+    x = R.gen_normal("poison:x", (B, T, d), 23).to(dev)
+    g = R.gen_normal("poison:g", (B, T, d), 23).to(dev)
+    mask = R.prefix_mask([max(1, T - 11 * i) for i in range(B)], T).to(dev)
+
+    def run():
+        xg, fg = x.clone().requires_grad_(), flat.clone().requires_grad_()
+        y = F.encoder_stack(xg, mask, fg, h, R.D_FF, 2, dropout_p=p, seed=77)
+        (y * g).sum().backward()
+        return y.detach().clone(), xg.grad.clone(), fg.grad.clone()
+
+    ref = run()
+    for pattern in (0x7FC00000, 0xFFFFFFFF):
+        F.poison_lds(dev, pattern)
+        for name, a, b in zip(("y", "dx", "dparams"), ref, run()):
+            assert torch.equal(a, b), "%s changed after LDS was filled with %08x" % (name, pattern)
