@@ -116,10 +116,20 @@ static int make_dims(EncDims& D, int B, int T, int d, int h, int f, int N) {
     D.M = B * T; D.MP = round_up(D.M, 64); D.M16 = round_up(D.M, 16);
     D.Tp = round_up(T, 32); D.nt = D.Tp / 32; D.G = (D.M + 31) / 32;
     D.L = make_layout(d, f, h);
-    // weight-gradient split over windows: ONE launch covers every layer; aim for >= 768 workgroups in it
+    // weight-gradient split over windows: ONE launch covers every layer.  The launch deals (layer, split) units of `tpl` tiles
+    // round-robin to the 8 XCDs (wgrad_kernel), and an XCD holds 32 CUs x 4 workgroups (36 KB of LDS each) at a time: pick the
+    // split count that minimises (dispatch rounds on the fullest XCD) x (64-window chunks per workgroup + overhead).
     const LayerLayout& L = D.L;
-    const int tiles = ((L.NQ / 64) * (L.DP / 64) + (L.DP / 64) * (L.HDP / 64) + 2 * (L.FP / 64) * (L.DP / 64)) * (N > 0 ? N : 1);
-    int s = (768 + tiles - 1) / tiles; if (s < 1) s = 1; if (s > 32) s = 32;
+    const int tpl = (L.NQ / 64) * (L.DP / 64) + (L.DP / 64) * (L.HDP / 64) + 2 * (L.FP / 64) * (L.DP / 64);
+    const int nl = N > 0 ? N : 1;
+    int s = 1; long best = -1;
+    for (int s2 = 1; s2 <= 32; ++s2) {
+        const int chunks = (round_up((D.MP + s2 - 1) / s2, 64)) / 64;
+        const int per_xcd = (nl * s2 + 7) / 8 * tpl;
+        // per workgroup ~4 chunk-times of prologue/slab store; per extra split ~0.7 chunk-times in the slab sums (measured, C4/C3e)
+        const long cost = (long)((per_xcd + 127) / 128) * (chunks + 4) * 10 + 7 * s2;
+        if (best < 0 || cost < best) { best = cost; s = s2; }
+    }
     D.mchunk = round_up((D.MP + s - 1) / s, 64);
     D.nsplit = (D.MP + D.mchunk - 1) / D.mchunk;
     return MMT_OK;
@@ -520,7 +530,9 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
     if (D.N > 0) {
         {   // every layer's weight and bias gradients: one launch
             ProfScope prof(S_WGRAD, st);
-            hipLaunchKernelGGL(wgrad_kernel, dim3(t0, D.nsplit), dim3(MMT_THREADS), 0, st, J);
+            J.tiles_per_layer = t0 / D.N; J.nlayers = D.N; J.nsplit = D.nsplit;         // XCD-aware 1-D grid (wgrad_kernel)
+            const int units = D.N * D.nsplit;
+            hipLaunchKernelGGL(wgrad_kernel, dim3(8 * ((units + 7) / 8) * J.tiles_per_layer), dim3(MMT_THREADS), 0, st, J);
         }
         LAUNCH_CHECK("wgrad_kernel");
         ProfScope prof(S_FINALIZE, st);

@@ -223,7 +223,8 @@ struct WgradJob {
     int NPj, KPj, tile0, tiles_k;
 };
 #define MMT_MAX_WGRAD_JOBS 64
-struct WgradJobs { WgradJob j[MMT_MAX_WGRAD_JOBS]; int njobs; int MP; int M16; int mchunk; };
+struct WgradJobs { WgradJob j[MMT_MAX_WGRAD_JOBS]; int njobs; int MP; int M16; int mchunk;
+                   int tiles_per_layer, nlayers, nsplit; };    // > 0: 1-D XCD-aware grid (see wgrad_kernel); 0: grid = (tiles, splits)
 
 __global__ __launch_bounds__(MMT_THREADS, 2) void wgrad_kernel(const WgradJobs jobs) {
     // Operand tiles [64 features][64 windows] are fetched with full 128-byte lines (8 lanes x 16 B per feature row),
@@ -232,13 +233,26 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void wgrad_kernel(const WgradJobs j
     constexpr int LDR = 72;                                    // bf16 elements per LDS row
     __shared__ __attribute__((aligned(16))) bf16 As[2][64 * LDR];
     __shared__ __attribute__((aligned(16))) bf16 Bs[2][64 * LDR];
+    // Workgroup -> (tile, window split).  The tiles of one layer and one window split read the same eight T-layout operands (every
+    // operand row block is shared by 2..6 tiles).  Consecutive workgroup ids go round-robin to the 8 XCDs, each with a private
+    // L2, so with a plain (tile, split) grid no two sharers met in an L2 and FETCH_SIZE was 2.7x the operand bytes.  The
+    // encoder launch uses a 1-D grid in which ids congruent mod 8 — one XCD — carry whole (layer, split) units one after the
+    // other.
+    int tile_g = blockIdx.x, split = blockIdx.y;
+    if (jobs.tiles_per_layer > 0) {
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        const int uix = slot / jobs.tiles_per_layer, tix = slot - uix * jobs.tiles_per_layer;
+        const int unit = uix * 8 + xcd;
+        if (unit >= jobs.nlayers * jobs.nsplit) return;         // whole workgroup, before any barrier
+        split = unit / jobs.nlayers;
+        tile_g = (unit - split * jobs.nlayers) * jobs.tiles_per_layer + tix;
+    }
     int ji = 0;
-    for (int i = 1; i < jobs.njobs; ++i) if ((int)blockIdx.x >= jobs.j[i].tile0) ji = i;
+    for (int i = 1; i < jobs.njobs; ++i) if (tile_g >= jobs.j[i].tile0) ji = i;
     const WgradJob& J = jobs.j[ji];
-    const int tile = blockIdx.x - J.tile0, tn = tile / J.tiles_k, tk = tile - tn * J.tiles_k;
+    const int tile = tile_g - J.tile0, tn = tile / J.tiles_k, tk = tile - tn * J.tiles_k;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int wn = wave >> 1, wk = wave & 1;
-    const int split = blockIdx.y;
     const int mbeg = split * jobs.mchunk, mend = min(jobs.MP, mbeg + jobs.mchunk);
     // staging role of this thread: rows row0 and row0+32 of each tile, 16-byte segment seg
     const int row0 = tid >> 3, seg = tid & 7;
