@@ -40,6 +40,13 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() would also drain vmcnt(0), i.e. wait at every
+// step for loads prefetched for later steps and for the step's output stores (cdna_hip_programming.md §5 "Pipelining across
+// barriers").  Used where data reaches LDS through registers (the ds_write's own register dependency waits for its load).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // row index (0..31) of accumulator register `reg` of a 32x32 MFMA result for lane-half hh
 __device__ __forceinline__ int acc32_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 

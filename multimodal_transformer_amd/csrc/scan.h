@@ -12,13 +12,6 @@
 #pragma once
 #include "common.h"
 
-// Workgroup barrier for the scans: waits for this wave's LDS traffic only.  __syncthreads() would also drain vmcnt(0),
-// i.e. wait at EVERY time step for the prefetched inputs of later steps and for the step's output stores
-// (cdna_hip_programming.md §5 "Pipelining across barriers").
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp2(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float tanh_f(float x) { return 2.0f * sigmoid_f(2.0f * x) - 1.0f; }
 
