@@ -166,6 +166,11 @@ int mmt_debug_dropout_mask(float p, uint64_t seed, uint32_t stream_id, uint64_t 
  * not write; tests run a workload, poison, run it again and require identical results.  `sink4`: any 4 writable device bytes. */
 int mmt_debug_poison_lds(uint32_t pattern, void* sink4, mmt_stream_t stream);
 
+/* ---- Test hook: `workgroups` workgroups each hold a pattern in `bytes` of LDS for about spins x 50 us and re-check it;
+ * bad2[0] += words found changed, bad2[1] += workgroups run (two device uint32).  Platform probe: LDS must survive queue
+ * time-slicing between processes (tools/lds_hold_probe.py). */
+int mmt_debug_lds_hold(int bytes, int spins, int workgroups, void* bad2, mmt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1105,6 +1105,29 @@ extern "C" int mmt_debug_poison_lds(uint32_t pattern, void* sink4, mmt_stream_t 
     return MMT_OK;
 }
 
+// Test hook: does a workgroup's LDS survive whatever the platform does to a running kernel (queue time-slicing between processes
+// saves and restores waves)?  Each workgroup writes a position-dependent pattern over `bytes` of LDS, idles for `spins` x ~50 us,
+// re-reads it and adds the number of wrong words to *bad (and 1 to bad[1] per workgroup that ran).
+__global__ __launch_bounds__(256) void lds_hold_kernel(int words, int spins, unsigned* bad) {
+    extern __shared__ uint32_t hold_smem[];
+    const uint32_t salt = 0x9E3779B9u * (blockIdx.x + 1);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) hold_smem[i] = salt ^ (uint32_t)i * 2654435761u;
+    __syncthreads();
+    for (int s = 0; s < spins; ++s) { for (int k = 0; k < 1000; ++k) __builtin_amdgcn_s_sleep(127); }   // ~64 x 127 x 1000 cycles
+    __syncthreads();
+    unsigned wrong = 0;
+    for (int i = threadIdx.x; i < words; i += blockDim.x) wrong += (hold_smem[i] != (salt ^ (uint32_t)i * 2654435761u));
+    if (wrong) atomicAdd(bad, wrong);
+    if (threadIdx.x == 0) atomicAdd(bad + 1, 1u);
+}
+extern "C" int mmt_debug_lds_hold(int bytes, int spins, int workgroups, void* bad2, mmt_stream_t stream) {
+    if (!bad2 || bytes < 4 || bytes > 160 * 1024) return fail(MMT_EINVAL, "bad argument");
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_hold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(lds_hold_kernel, dim3(workgroups), dim3(256), bytes, static_cast<hipStream_t>(stream), bytes / 4, spins, static_cast<unsigned*>(bad2));
+    LAUNCH_CHECK("lds_hold_kernel");
+    return MMT_OK;
+}
+
 extern "C" int mmt_debug_dropout_mask(float p, uint64_t seed, uint32_t stream_id, uint64_t n, uint32_t attn_Tp, uint8_t* keep,
                                       float* scale_out, mmt_stream_t stream) {
     if (!keep) return fail(MMT_EINVAL, "null pointer argument");
