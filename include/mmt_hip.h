@@ -170,6 +170,8 @@ int mmt_debug_poison_lds(uint32_t pattern, void* sink4, mmt_stream_t stream);
  * bad2[0] += words found changed, bad2[1] += workgroups run (two device uint32).  Platform probe: LDS must survive queue
  * time-slicing between processes (tools/lds_hold_probe.py). */
 int mmt_debug_lds_hold(int bytes, int spins, int workgroups, void* bad2, mmt_stream_t stream);
+/* the same for 224 vector registers per lane (kernels of this library use up to 256) */
+int mmt_debug_vgpr_hold(int spins, int workgroups, void* bad2, mmt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,7 @@ SIGNATURES = {
     "mmt_debug_dropout_mask": (_I, [_F, _U64, _c.c_uint32, _U64, _c.c_uint32, _P, _P, _P]),
     "mmt_debug_poison_lds": (_I, [_c.c_uint32, _P, _P]),
     "mmt_debug_lds_hold": (_I, [_I, _I, _I, _P, _P]),
+    "mmt_debug_vgpr_hold": (_I, [_I, _I, _P, _P]),
 }
 
 _lib = None

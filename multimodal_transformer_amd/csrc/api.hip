@@ -1120,6 +1120,28 @@ __global__ __launch_bounds__(256) void lds_hold_kernel(int words, int spins, uns
     if (wrong) atomicAdd(bad, wrong);
     if (threadIdx.x == 0) atomicAdd(bad + 1, 1u);
 }
+// Same question for the vector registers: every lane holds 224 distinct values in VGPRs (made opaque so they are neither
+// recomputed nor reloaded) across the idle time.
+__global__ __launch_bounds__(256, 2) void vgpr_hold_kernel(int spins, unsigned* bad) {
+    constexpr int NR = 224;
+    uint32_t r[NR];
+    const uint32_t salt = 0x85EBCA6Bu * (blockIdx.x * 256 + threadIdx.x + 1);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { r[i] = salt ^ (uint32_t)(i + 1) * 2654435761u; asm volatile("" : "+v"(r[i])); }
+    for (int s = 0; s < spins; ++s) { for (int k = 0; k < 1000; ++k) __builtin_amdgcn_s_sleep(127); }
+    unsigned wrong = 0;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { asm volatile("" : "+v"(r[i])); wrong += (r[i] != (salt ^ (uint32_t)(i + 1) * 2654435761u)); }
+    if (wrong) atomicAdd(bad, wrong);
+    if (threadIdx.x == 0) atomicAdd(bad + 1, 1u);
+}
+extern "C" int mmt_debug_vgpr_hold(int spins, int workgroups, void* bad2, mmt_stream_t stream) {
+    if (!bad2) return fail(MMT_EINVAL, "null pointer argument");
+    hipLaunchKernelGGL(vgpr_hold_kernel, dim3(workgroups), dim3(256), 0, static_cast<hipStream_t>(stream), spins, static_cast<unsigned*>(bad2));
+    LAUNCH_CHECK("vgpr_hold_kernel");
+    return MMT_OK;
+}
+
 extern "C" int mmt_debug_lds_hold(int bytes, int spins, int workgroups, void* bad2, mmt_stream_t stream) {
     if (!bad2 || bytes < 4 || bytes > 160 * 1024) return fail(MMT_EINVAL, "bad argument");
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_hold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -17,3 +17,10 @@ for kb in (32, 60, 64, 68, 96, 150, 160):
     torch.cuda.synchronize()
     b = bad.cpu().tolist()
     print("LDS %3d KB: %d workgroups ran, %d words changed" % (kb, b[1], b[0]), flush=True)
+
+bad = torch.zeros(2, dtype=torch.int32, device=dev)
+for rep in range(40):
+    _lib.check(lib.mmt_debug_vgpr_hold(8, 1024, _lib.ptr(bad), _lib.stream_ptr()))
+torch.cuda.synchronize()
+b = bad.cpu().tolist()
+print("VGPRs (224 per lane): %d workgroups ran, %d registers changed" % (b[1], b[0]), flush=True)
