@@ -1128,8 +1128,10 @@ __global__ __launch_bounds__(256, 2) void vgpr_hold_kernel(int spins, unsigned* 
     const uint32_t salt = 0x85EBCA6Bu * (blockIdx.x * 256 + threadIdx.x + 1);
 #pragma unroll
     for (int i = 0; i < NR; ++i) { r[i] = salt ^ (uint32_t)(i + 1) * 2654435761u; asm volatile("" : "+v"(r[i])); }
+    const uint32_t mode0 = __builtin_amdgcn_s_getreg((31 << 11) | 1);      // HW_REG_MODE: rounding / denormal / exception bits
     for (int s = 0; s < spins; ++s) { for (int k = 0; k < 1000; ++k) __builtin_amdgcn_s_sleep(127); }
-    unsigned wrong = 0;
+    const uint32_t mode1 = __builtin_amdgcn_s_getreg((31 << 11) | 1);
+    unsigned wrong = (mode0 != mode1) ? 1000000u : 0u;                      // a changed MODE register counts a million
 #pragma unroll
     for (int i = 0; i < NR; ++i) { asm volatile("" : "+v"(r[i])); wrong += (r[i] != (salt ^ (uint32_t)(i + 1) * 2654435761u)); }
     if (wrong) atomicAdd(bad, wrong);
