@@ -162,8 +162,8 @@ int mmt_convpool_backward(const float* x, const float* dout, const int32_t* argm
 int mmt_debug_dropout_mask(float p, uint64_t seed, uint32_t stream_id, uint64_t n, uint32_t attn_Tp, uint8_t* keep,
                            float* host_scale_out, mmt_stream_t stream);
 
-/* ---- Test hook: fill every LDS word of every CU with `pattern` (e.g. 0x7FC00000, a NaN).  Kernels must not depend on LDS they did
- * not write; tests run a workload, poison, run it again and require identical results.  `sink4`: any 4 writable device bytes. */
+/* ---- Test hook: fill every LDS word of every CU, and the vector registers of every SIMD, with `pattern` (e.g. 0x7FC00000, a NaN).
+ * Kernels must not depend on LDS or registers they did not write; tests run a workload, poison, run it again and require identical results.  `sink4`: any 4 writable device bytes. */
 int mmt_debug_poison_lds(uint32_t pattern, void* sink4, mmt_stream_t stream);
 
 /* ---- Test hook: `workgroups` workgroups each hold a pattern in `bytes` of LDS for about spins x 50 us and re-check it;

@@ -1093,6 +1093,18 @@ __global__ __launch_bounds__(1024) void poison_lds_kernel(uint32_t pattern, int 
     for (int i = threadIdx.x; i < words; i += blockDim.x * 7) acc ^= poison_smem[i];
     if (acc == 0x12345u) sink[0] = acc;
 }
+// ... and in the vector registers: a wave starts with whatever the previous wave on its SIMD slot left there.
+__global__ __launch_bounds__(256, 2) void poison_vgpr_kernel(uint32_t pattern, uint32_t* sink) {
+    constexpr int NR = 232;
+    uint32_t r[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { r[i] = pattern; asm volatile("" : "+v"(r[i])); }
+    __builtin_amdgcn_s_sleep(64);
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { asm volatile("" : "+v"(r[i])); acc += r[i] ^ (uint32_t)i; }
+    if (acc == 0x12345u) sink[0] = acc;
+}
 extern "C" int mmt_debug_poison_lds(uint32_t pattern, void* sink4, mmt_stream_t stream) {
     if (!sink4) return fail(MMT_EINVAL, "null pointer argument");
     static bool configured = false;
@@ -1102,6 +1114,8 @@ extern "C" int mmt_debug_poison_lds(uint32_t pattern, void* sink4, mmt_stream_t 
     }
     hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(1024), 160 * 1024, static_cast<hipStream_t>(stream), pattern, 160 * 256, static_cast<uint32_t*>(sink4));
     LAUNCH_CHECK("poison_lds_kernel");
+    hipLaunchKernelGGL(poison_vgpr_kernel, dim3(8192), dim3(256), 0, static_cast<hipStream_t>(stream), pattern, static_cast<uint32_t*>(sink4));
+    LAUNCH_CHECK("poison_vgpr_kernel");
     return MMT_OK;
 }
 
