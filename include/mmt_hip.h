@@ -170,8 +170,14 @@ int mmt_debug_poison_lds(uint32_t pattern, void* sink4, mmt_stream_t stream);
  * bad2[0] += words found changed, bad2[1] += workgroups run (two device uint32).  Platform probe: LDS must survive queue
  * time-slicing between processes (tools/lds_hold_probe.py). */
 int mmt_debug_lds_hold(int bytes, int spins, int workgroups, void* bad2, mmt_stream_t stream);
+/* ---- Test hook: 64-bit word sums of twelve intermediate buffers of layer 0 in the encoder workspace after a backward call
+ * (dx2T, dhT, dxa, dxb, lnpart2, dO R, dO T, delta, dx1T, dqkv, dqkvT, lnpart1): which one differs first between two runs. */
+int mmt_debug_encoder_bwd_checksums(void* workspace, int B, int T, int d, int h, int d_ff, int n_layers,
+                                    unsigned long long* out12, mmt_stream_t stream);
 /* the same for 224 vector registers per lane (kernels of this library use up to 256) */
 int mmt_debug_vgpr_hold(int spins, int workgroups, void* bad2, mmt_stream_t stream);
+/* and for arithmetic: fp32 division, lane-shuffle sums and FMAs repeated `iters` times on fixed inputs must always give the same bits */
+int mmt_debug_compute_hold(int iters, int workgroups, void* bad2, mmt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,8 @@ SIGNATURES = {
     "mmt_debug_poison_lds": (_I, [_c.c_uint32, _P, _P]),
     "mmt_debug_lds_hold": (_I, [_I, _I, _I, _P, _P]),
     "mmt_debug_vgpr_hold": (_I, [_I, _I, _P, _P]),
+    "mmt_debug_compute_hold": (_I, [_I, _I, _P, _P]),
+    "mmt_debug_encoder_bwd_checksums": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
 }
 
 _lib = None

@@ -1082,6 +1082,35 @@ __global__ void dropout_mask_kernel(DropCfg c, uint64_t n, uint32_t attn_Tp, uin
         keep[i] = (((idx & 1) ? (w >> 16) : (w & 0xFFFFu)) >= c.thr16) ? 1 : 0;
     }
 }
+// Test hook: order-independent checksums (64-bit sums of 32-bit words) of the backward pass's intermediate buffers of layer 0,
+// read from the workspace after mmt_encoder_backward: which buffer is the first to differ between two runs?
+__global__ void checksum_kernel(const uint32_t* __restrict__ src, size_t words, unsigned long long* out) {
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) acc += src[i];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+extern "C" int mmt_debug_encoder_bwd_checksums(void* workspace, int B, int T, int d, int h, int d_ff, int n_layers,
+                                               unsigned long long* out12, mmt_stream_t stream) {
+    EncDims D; int rc = make_dims(D, B, T, d, h, d_ff, n_layers);
+    if (rc) return rc;
+    if (!workspace || !out12 || n_layers < 1) return fail(MMT_EINVAL, "bad argument");
+    EncWs W; carve_encoder(W, D, workspace);
+    const LayerLayout& L = D.L; const LayerWs& w = W.lw[0];
+    const size_t M = D.M, MP = D.MP, BH = (size_t)D.B * D.h;
+    const void* ptr[12] = {w.dx2T, w.dhT, W.dxa, W.dxb, w.lnpart2, W.dOR, W.dOT, W.delta, w.dx1T, W.dqkv, w.dqkvT, w.lnpart1};
+    const size_t bytes[12] = {(size_t)L.DP * MP * 2, (size_t)L.FP * MP * 2, M * D.d * 4, M * D.d * 4, (size_t)D.G * 2 * L.DP * 4,
+                              BH * fragR_elems(D.Tp, L.DKP) * 2, BH * fragT_elems(D.Tp) * 2, BH * D.Tp * 4, (size_t)L.DP * MP * 2,
+                              M * L.NQ * 2, (size_t)L.NQ * MP * 2, (size_t)D.G * 2 * L.DP * 4};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(out12, 0, 12 * sizeof(unsigned long long), st));
+    for (int i = 0; i < 12; ++i) {
+        hipLaunchKernelGGL(checksum_kernel, dim3(512), dim3(256), 0, st, static_cast<const uint32_t*>(ptr[i]), bytes[i] / 4, out12 + i);
+        LAUNCH_CHECK("checksum_kernel");
+    }
+    return MMT_OK;
+}
+
 // Test hook: leave a chosen bit pattern in every LDS word (and a spread of VGPRs) of every CU.  A kernel whose result depends on LDS
 // it never wrote (what a freshly powered GPU hands it: the first process on a box) then produces a different answer after this call.
 __global__ __launch_bounds__(1024) void poison_lds_kernel(uint32_t pattern, int words, uint32_t* sink) {
@@ -1151,6 +1180,35 @@ __global__ __launch_bounds__(256, 2) void vgpr_hold_kernel(int spins, unsigned* 
     if (wrong) atomicAdd(bad, wrong);
     if (threadIdx.x == 0) atomicAdd(bad + 1, 1u);
 }
+// ... and for arithmetic: every lane repeats the operations of the LayerNorm-backward epilogue (IEEE fp32 division, 8-lane
+// butterfly sums through __shfl_xor, fused multiply-adds) on fixed inputs many times and compares each result with the first one.
+__device__ __attribute__((noinline)) float compute_hold_once(float x, float y) {
+    float s1 = x * y, s2 = x - y;
+    s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+    s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
+    const float sigma = 1.0f / y - 1e-6f;
+    const float k1 = s1 / 128.0f, k2 = s2 / (127.0f * sigma);
+    return y * (x * 1.25f - k1) - k2 * (x - 0.5f) + y;
+}
+__global__ __launch_bounds__(256, 2) void compute_hold_kernel(int iters, unsigned* bad) {
+    float a = 1.0f + 0.001f * (float)(threadIdx.x + 1), b = 3.0f + 0.01f * (float)(blockIdx.x % 97);
+    asm volatile("" : "+v"(a), "+v"(b));
+    const uint32_t ref = __float_as_uint(compute_hold_once(a, b));      // the same out-of-line code every time
+    unsigned wrong = 0;
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("" : "+v"(a), "+v"(b));
+        wrong += (__float_as_uint(compute_hold_once(a, b)) != ref);
+    }
+    if (wrong) atomicAdd(bad, wrong);
+    if (threadIdx.x == 0) atomicAdd(bad + 1, 1u);
+}
+extern "C" int mmt_debug_compute_hold(int iters, int workgroups, void* bad2, mmt_stream_t stream) {
+    if (!bad2) return fail(MMT_EINVAL, "null pointer argument");
+    hipLaunchKernelGGL(compute_hold_kernel, dim3(workgroups), dim3(256), 0, static_cast<hipStream_t>(stream), iters, static_cast<unsigned*>(bad2));
+    LAUNCH_CHECK("compute_hold_kernel");
+    return MMT_OK;
+}
+
 extern "C" int mmt_debug_vgpr_hold(int spins, int workgroups, void* bad2, mmt_stream_t stream) {
     if (!bad2) return fail(MMT_EINVAL, "null pointer argument");
     hipLaunchKernelGGL(vgpr_hold_kernel, dim3(workgroups), dim3(256), 0, static_cast<hipStream_t>(stream), spins, static_cast<unsigned*>(bad2));

@@ -24,3 +24,10 @@ for rep in range(40):
 torch.cuda.synchronize()
 b = bad.cpu().tolist()
 print("VGPRs (224 per lane): %d workgroups ran, %d registers changed" % (b[1], b[0]), flush=True)
+
+bad = torch.zeros(2, dtype=torch.int32, device=dev)
+for rep in range(40):
+    _lib.check(lib.mmt_debug_compute_hold(100000, 2048, _lib.ptr(bad), _lib.stream_ptr()))
+torch.cuda.synchronize()
+b = bad.cpu().tolist()
+print("arithmetic (division, shuffles, FMA): %d workgroups ran, %d results changed" % (b[1], b[0]), flush=True)
