@@ -8,8 +8,10 @@ import torch
 from multimodal_transformer_amd import _lib
 from multimodal_transformer_amd import multiTransformer as MT
 
-B, T, d, h, f, N = 32, 500, 128, 8, 128, 1
+B, T, d, h, f = 32, 500, 128, 8, 128
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+PDROP = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0       # > 0: train mode with a fixed seed
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 NAMES = ["dx2T", "dhT", "dxa(cur: LN-bwd out)", "dxb(other: dx1)", "lnpart2", "dO R", "dO T", "delta", "dx1T", "dqkv", "dqkvT", "lnpart1"]
 lib = _lib.load()
 dev = torch.device("cuda:0")
@@ -30,9 +32,9 @@ st = _lib.stream_ptr()
 
 
 def run():
-    _lib.check(lib.mmt_encoder_forward(_lib.ptr(x), _lib.ptr(mask), _lib.ptr(flat), _lib.ptr(y), _lib.ptr(ws), nbytes, B, T, d, h, f, N, 1e-6, 0.0, 0, st))
+    _lib.check(lib.mmt_encoder_forward(_lib.ptr(x), _lib.ptr(mask), _lib.ptr(flat), _lib.ptr(y), _lib.ptr(ws), nbytes, B, T, d, h, f, N, 1e-6, PDROP, 77, st))
     _lib.check(lib.mmt_encoder_backward(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(mask), _lib.ptr(flat), _lib.ptr(dx), _lib.ptr(dp), _lib.ptr(ws), nbytes,
-                                        B, T, d, h, f, N, 1e-6, 0.0, 0, st))
+                                        B, T, d, h, f, N, 1e-6, PDROP, 77, st))
     _lib.check(lib.mmt_debug_encoder_bwd_checksums(_lib.ptr(ws), B, T, d, h, f, N, _lib.ptr(sums), st))
     torch.cuda.synchronize()
     return sums.cpu().tolist(), dx.clone()
