@@ -110,7 +110,11 @@ int mmt_linear_backward(const float* dy, const float* x, const float* W, const f
  * and the per-step nn.LSTM call of the SFT decoder            transformer/SFT/multiTransformer.py:471-476.
  * gx (T,B,4H) = x_t W_ih^T + b_ih + b_hh (gate order i,f,g,o); W_rec (4H,H) multiplies h_{t-1};
  * h0,c0 (B,H) or NULL (zeros).  Outputs h_all, c_all (T,B,H) and the gate activations acts (T,B,4H)
- * kept for the backward.  H % 4 == 0, H <= 256.  act codes elsewhere: 0 none, 1 ReLU, 2 tanh, 3 sigmoid. */
+ * kept for the backward.  H % 4 == 0, H <= 256.
+ * Device error word: the first uint32 of `workspace` is zeroed by every call and is non-zero once the kernels have run
+ * if a scan for H > 128 (four workgroups per sequence exchanging h through memory) timed out waiting for a partner
+ * workgroup — e.g. another process held the CUs.  The outputs are then INVALID.  Nothing synchronises here: read the word
+ * after the stream has drained (the Python wrapper does, functional.check_device_errors()). */
 size_t mmt_lstm_scan_workspace_bytes(int H);
 int mmt_lstm_scan_forward(const float* gx, const float* W_rec, const float* h0, const float* c0,
                           float* h_all, float* c_all, float* acts, void* workspace, size_t workspace_bytes,
@@ -165,19 +169,6 @@ int mmt_debug_dropout_mask(float p, uint64_t seed, uint32_t stream_id, uint64_t 
 /* ---- Test hook: fill every LDS word of every CU, and the vector registers of every SIMD, with `pattern` (e.g. 0x7FC00000, a NaN).
  * Kernels must not depend on LDS or registers they did not write; tests run a workload, poison, run it again and require identical results.  `sink4`: any 4 writable device bytes. */
 int mmt_debug_poison_lds(uint32_t pattern, void* sink4, mmt_stream_t stream);
-
-/* ---- Test hook: `workgroups` workgroups each hold a pattern in `bytes` of LDS for about spins x 50 us and re-check it;
- * bad2[0] += words found changed, bad2[1] += workgroups run (two device uint32).  Platform probe: LDS must survive queue
- * time-slicing between processes (tools/lds_hold_probe.py). */
-int mmt_debug_lds_hold(int bytes, int spins, int workgroups, void* bad2, mmt_stream_t stream);
-/* ---- Test hook: 64-bit word sums of twelve intermediate buffers of layer 0 in the encoder workspace after a backward call
- * (dx2T, dhT, dxa, dxb, lnpart2, dO R, dO T, delta, dx1T, dqkv, dqkvT, lnpart1): which one differs first between two runs. */
-int mmt_debug_encoder_bwd_checksums(void* workspace, int B, int T, int d, int h, int d_ff, int n_layers,
-                                    unsigned long long* out12, mmt_stream_t stream);
-/* the same for 224 vector registers per lane (kernels of this library use up to 256) */
-int mmt_debug_vgpr_hold(int spins, int workgroups, void* bad2, mmt_stream_t stream);
-/* and for arithmetic: fp32 division, lane-shuffle sums and FMAs repeated `iters` times on fixed inputs must always give the same bits */
-int mmt_debug_compute_hold(int iters, int workgroups, void* bad2, mmt_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -48,10 +48,6 @@ SIGNATURES = {
     "mmt_convpool_backward": (_I, [_P] * 6 + [_SZ] + [_I] * 4 + [_P]),
     "mmt_debug_dropout_mask": (_I, [_F, _U64, _c.c_uint32, _U64, _c.c_uint32, _P, _P, _P]),
     "mmt_debug_poison_lds": (_I, [_c.c_uint32, _P, _P]),
-    "mmt_debug_lds_hold": (_I, [_I, _I, _I, _P, _P]),
-    "mmt_debug_vgpr_hold": (_I, [_I, _I, _P, _P]),
-    "mmt_debug_compute_hold": (_I, [_I, _I, _P, _P]),
-    "mmt_debug_encoder_bwd_checksums": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
 }
 
 _lib = None
@@ -123,27 +119,128 @@ class WorkspacePool:
     def __init__(self):
         self._free = {}
         self._home = {}
+        self._mutex = threading.Lock()
 
     def get(self, nbytes, device, tag=None):
-        """``tag`` distinguishes call sites whose workspaces have the same size but a different internal layout (the zero
-        pads of one would be live data of the other)."""
+        """``tag`` names the call site AND its shape: two shapes can need the same number of bytes with a different internal
+        layout (measured: (B=4,T=50) and (B=2,T=100) encoder workspaces are both 6,158,080 bytes), and the zero pads of one
+        would then be live data of the other.  Every caller passes one."""
         key = (str(device), SIDE_LANES.get(int(torch.cuda.current_stream(device).cuda_stream), 0), int(nbytes), tag)
-        lst = self._free.get(key)
-        buf = lst.pop() if lst else torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
-        self._home[buf.data_ptr()] = key
+        with self._mutex:
+            lst = self._free.get(key)
+            buf = lst.pop() if lst else None
+        if buf is None:
+            buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        with self._mutex:
+            self._home[buf.data_ptr()] = key
         return buf
 
     def put(self, buf):
-        key = self._home.get(buf.data_ptr())
-        if key is not None:
-            self._free.setdefault(key, []).append(buf)
+        with self._mutex:
+            key = self._home.get(buf.data_ptr())
+            if key is not None:
+                self._free.setdefault(key, []).append(buf)
 
     def clear(self):
-        self._free.clear()
-        self._home.clear()
+        with self._mutex:
+            self._free.clear()
+            self._home.clear()
 
 
 POOL = WorkspacePool()
+
+
+class DeviceErrorWatch:
+    """Device error words of asynchronous kernels (today: the exchange time-out of the four-CU LSTM scans,
+    include/mmt_hip.h mmt_lstm_scan_*).  ``watch`` copies the word to pinned host memory behind the launch and records an
+    event; ``poll`` (called at every later launch, never blocking) and ``check`` (blocking) raise if a drained launch left
+    a non-zero word.  Inside a hipGraph capture the copy becomes a node of the graph: every replay refreshes the host word,
+    which ``check`` reads after the caller's synchronisation."""
+
+    def __init__(self):
+        self._pending = []          # (host word, event or None, description)
+        self._captured = []
+        self._mutex = threading.Lock()
+
+    def watch(self, dev_word, what):
+        host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        host.copy_(dev_word, non_blocking=True)
+        capturing = torch.cuda.is_current_stream_capturing()
+        ev = None
+        if not capturing:
+            ev = torch.cuda.Event()
+            ev.record()
+        with self._mutex:
+            (self._captured if capturing else self._pending).append((host, ev, what))
+        self.poll()
+
+    @staticmethod
+    def _raise(what):
+        raise RuntimeError("libmmt_hip device error: %s timed out waiting for a partner workgroup (CUs held by another stream "
+                           "or process?); its outputs are invalid.  MMT_NO_CLUSTER_SCAN=1 selects the one-CU scan." % what)
+
+    def poll(self):
+        with self._mutex:
+            done, rest = [], []
+            for e in self._pending:
+                (done if e[1].query() else rest).append(e)
+            self._pending = rest
+        for host, _, what in done:
+            if int(host[0]) != 0:
+                self._raise(what)
+
+    def check(self):
+        """Synchronise the device and raise if any watched launch (eager or replayed from a graph) reported an error."""
+        torch.cuda.synchronize()
+        with self._mutex:
+            entries, self._pending = self._pending + self._captured, []
+        for host, _, what in entries:
+            if int(host[0]) != 0:
+                self._raise(what)
+
+
+ERRORS = DeviceErrorWatch()
+
+_seed_fallback_counter = [0]
+
+
+def mix64(*words):
+    """splitmix64 chain over integer words -> 63-bit seed (host side; the kernels mix it again per stream)."""
+    z = 0x243F6A8885A308D3
+    for w in words:
+        z = (z + (int(w) & 0xFFFFFFFFFFFFFFFF) + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 31
+    return z & 0x7FFFFFFFFFFFFFFF
+
+
+def next_dropout_seed(device, site):
+    """Seed of one train-mode forward of one module.  Like torch's own dropout kernels it is drawn from the DEVICE generator
+    (seed, offset) and advances the offset, so: every call of every module instance gets fresh masks (the three modality
+    encoders of the MFT no longer share them), a run restored with its RNG state continues its mask sequence instead of
+    replaying it from step 1, and torch.manual_seed() controls it.  The data-parallel rank is mixed in: ranks seeded alike
+    still drop different units.  During hipGraph capture the generator cannot be advanced on the host; a
+    process-wide counter stands in (the captured seed is frozen under replay anyway: bench only)."""
+    rank = 0
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            rank = dist.get_rank()
+    except Exception:  # noqa: BLE001
+        rank = 0
+    base, off = torch.initial_seed(), None
+    try:
+        if device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+            base, off = gen.initial_seed(), gen.get_offset()
+            gen.set_offset(off + 4)                 # philox offsets advance in multiples of 4
+    except Exception:  # noqa: BLE001
+        off = None
+    if off is None:
+        _seed_fallback_counter[0] += 1
+        off = (1 << 40) + _seed_fallback_counter[0]
+    return mix64(base, off, rank, site)
 
 
 def profile(on):

@@ -818,20 +818,33 @@ extern "C" int mmt_linear_backward(const float* dy, const float* x, const float*
 
 
 // ------------------------------------------------------------------------------------ LSTM scan
-struct LstmWs { bf16 *Wf, *Wb; cl_u64* xb; size_t xb_bytes; int HP16, HPAD; size_t bytes; };
+struct LstmWs { unsigned* err; cl_u64* xb; bf16 *Wf, *Wb; size_t xb_bytes; int HP16, HPAD; size_t bytes; };
+#define MMT_SCAN_ERR_BYTES 256            // error block at workspace offset 0 (word 0: exchange time-out of the four-CU scans)
 static int carve_lstm(LstmWs& W, int H, void* base) {
     if (H <= 0 || H > 256) return fail(MMT_EUNSUPPORTED, "LSTM hidden size %d not in [4,256]", H);
     if (H % 4) return fail(MMT_EUNSUPPORTED, "LSTM hidden size %d must be a multiple of 4", H);
     W.HP16 = round_up(H, 16);
     W.HPAD = W.HP16 <= 64 ? 64 : (W.HP16 <= 128 ? 128 : 256);
     Carver c(base);
-    W.Wf = c.take<bf16>((size_t)4 * W.HP16 * W.HPAD); W.Wb = c.take<bf16>((size_t)(W.HP16 + 16) * 4 * W.HPAD);   // +16 rows: scan256 reads a ragged tile whole
+    W.err = c.take<unsigned>(MMT_SCAN_ERR_BYTES / sizeof(unsigned));     // FIRST: callers read the error word at offset 0
     W.xb_bytes = W.HPAD == 256 ? (size_t)32 * 2 * CL_NP * 128 * sizeof(cl_u64) : 0;   // exchange granules of the 4-CU scans (<= 32 sequences)
-    W.xb = c.take<cl_u64>(W.xb_bytes / sizeof(cl_u64));
+    W.xb = c.take<cl_u64>(W.xb_bytes / sizeof(cl_u64));                  // directly behind it: one memset node clears both
+    W.Wf = c.take<bf16>((size_t)4 * W.HP16 * W.HPAD); W.Wb = c.take<bf16>((size_t)(W.HP16 + 16) * 4 * W.HPAD);   // +16 rows: scan256 reads a ragged tile whole
     W.bytes = c.off;
     return MMT_OK;
 }
 extern "C" size_t mmt_lstm_scan_workspace_bytes(int H) { LstmWs W; return carve_lstm(W, H, nullptr) ? 0 : W.bytes; }
+
+// The four-CU scans (scan_cluster.h) need the four workgroups of every sequence resident together.  Take that path only when the
+// occupancy query admits at least TWICE the grid on this device (margin for kernels of other streams); anything that still goes
+// wrong at run time (another process holding the CUs) ends in the kernels' bounded waits and the workspace's error word.
+template <typename K> static bool cl4_resident(K kernel, int grid) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kernel), 256, 0) != hipSuccess) return false;
+    return (long)per_cu * cus >= 2L * grid;
+}
 
 // sequences per scan workgroup: the smallest power of two that still fits the batch into <= 256 workgroups (one per CU)
 static int scan_bt(int B) { int bt = 1; while (bt < 16 && (B + bt - 1) / bt > 256) bt *= 2; return bt; }
@@ -858,10 +871,13 @@ extern "C" int mmt_lstm_scan_forward(const float* gx, const float* W_rec, const 
 #define MMT_LSTM_FWD(KS, NT, WREG, PF, COOP) hipLaunchKernelGGL((lstm_scan_fwd_kernel<KS, NT, WREG, PF, COOP>), grid, block, 0, st, \
         gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, BT)
     static const bool no_cluster = getenv("MMT_NO_CLUSTER_SCAN") != nullptr;
-    if (W.HPAD == 256 && B <= 32 && !no_cluster) {       // four CUs per sequence, weights fully register-resident (scan_cluster.h)
-        HIP_TRY(hipMemsetAsync(W.xb, 0, W.xb_bytes, st));
-        hipLaunchKernelGGL((lstm_scan_fwd_cl4_kernel<3>), dim3(32 * ((B + 7) / 8)), dim3(256), 0, st,
-                           gx, W.Wf, h0, c0, h_all, c_all, acts, W.xb, T, B, H, W.HP16);
+    const int cl_grid = 32 * ((B + 7) / 8);
+    static const int cl_fit = cl4_resident(&lstm_scan_fwd_cl4_kernel<3>, 128) ? 1 : 0;        // the largest grid this path launches
+    const bool cluster = W.HPAD == 256 && B <= 32 && !no_cluster && cl_fit;
+    HIP_TRY(hipMemsetAsync(W.err, 0, MMT_SCAN_ERR_BYTES + (cluster ? W.xb_bytes : 0), st));    // error word (+ exchange granules)
+    if (cluster) {       // four CUs per sequence, weights fully register-resident (scan_cluster.h)
+        hipLaunchKernelGGL((lstm_scan_fwd_cl4_kernel<3>), dim3(cl_grid), dim3(256), 0, st,
+                           gx, W.Wf, h0, c0, h_all, c_all, acts, W.xb, W.err, T, B, H, W.HP16);
     } else if (W.HPAD == 256 && BT == 1) {   // half-resident weights, one sequence per workgroup (scan256.h)
         hipLaunchKernelGGL((lstm_scan_fwd256_kernel<4, 1>), dim3(B), dim3(64 * ((W.HP16 + 31) / 32)), 0, st,
                            gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16);
@@ -904,10 +920,12 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
 #define MMT_LSTM_BWD(KS4, NT, WREG, PF, COOP) hipLaunchKernelGGL((lstm_scan_bwd_kernel<KS4, NT, WREG, PF, COOP>), grid, block, lds, st, \
         dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, BT)
     static const bool no_cluster = getenv("MMT_NO_CLUSTER_SCAN") != nullptr;
-    if (W.HPAD == 256 && B <= 32 && !no_cluster) {
-        HIP_TRY(hipMemsetAsync(W.xb, 0, W.xb_bytes, st));
+    static const int cl_fit = cl4_resident(&lstm_scan_bwd_cl4_kernel<2>, 128) ? 1 : 0;
+    const bool cluster = W.HPAD == 256 && B <= 32 && !no_cluster && cl_fit;
+    HIP_TRY(hipMemsetAsync(W.err, 0, MMT_SCAN_ERR_BYTES + (cluster ? W.xb_bytes : 0), st));
+    if (cluster) {
         hipLaunchKernelGGL((lstm_scan_bwd_cl4_kernel<2>), dim3(32 * ((B + 7) / 8)), dim3(256), 0, st,
-                           dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, W.xb, T, B, H, W.HP16);
+                           dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, W.xb, W.err, T, B, H, W.HP16);
     } else if (W.HPAD == 256 && BT == 1) {
         static bool attr256 = false;
         if (!attr256) { if ((rc = set_lds_attr(&lstm_scan_bwd256_kernel<16, 1>))) return rc; attr256 = true; }
@@ -1082,35 +1100,6 @@ __global__ void dropout_mask_kernel(DropCfg c, uint64_t n, uint32_t attn_Tp, uin
         keep[i] = (((idx & 1) ? (w >> 16) : (w & 0xFFFFu)) >= c.thr16) ? 1 : 0;
     }
 }
-// Test hook: order-independent checksums (64-bit sums of 32-bit words) of the backward pass's intermediate buffers of layer 0,
-// read from the workspace after mmt_encoder_backward: which buffer is the first to differ between two runs?
-__global__ void checksum_kernel(const uint32_t* __restrict__ src, size_t words, unsigned long long* out) {
-    unsigned long long acc = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) acc += src[i];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
-}
-extern "C" int mmt_debug_encoder_bwd_checksums(void* workspace, int B, int T, int d, int h, int d_ff, int n_layers,
-                                               unsigned long long* out12, mmt_stream_t stream) {
-    EncDims D; int rc = make_dims(D, B, T, d, h, d_ff, n_layers);
-    if (rc) return rc;
-    if (!workspace || !out12 || n_layers < 1) return fail(MMT_EINVAL, "bad argument");
-    EncWs W; carve_encoder(W, D, workspace);
-    const LayerLayout& L = D.L; const LayerWs& w = W.lw[0];
-    const size_t M = D.M, MP = D.MP, BH = (size_t)D.B * D.h;
-    const void* ptr[12] = {w.dx2T, w.dhT, W.dxa, W.dxb, w.lnpart2, W.dOR, W.dOT, W.delta, w.dx1T, W.dqkv, w.dqkvT, w.lnpart1};
-    const size_t bytes[12] = {(size_t)L.DP * MP * 2, (size_t)L.FP * MP * 2, M * D.d * 4, M * D.d * 4, (size_t)D.G * 2 * L.DP * 4,
-                              BH * fragR_elems(D.Tp, L.DKP) * 2, BH * fragT_elems(D.Tp) * 2, BH * D.Tp * 4, (size_t)L.DP * MP * 2,
-                              M * L.NQ * 2, (size_t)L.NQ * MP * 2, (size_t)D.G * 2 * L.DP * 4};
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipMemsetAsync(out12, 0, 12 * sizeof(unsigned long long), st));
-    for (int i = 0; i < 12; ++i) {
-        hipLaunchKernelGGL(checksum_kernel, dim3(512), dim3(256), 0, st, static_cast<const uint32_t*>(ptr[i]), bytes[i] / 4, out12 + i);
-        LAUNCH_CHECK("checksum_kernel");
-    }
-    return MMT_OK;
-}
-
 // Test hook: leave a chosen bit pattern in every LDS word (and a spread of VGPRs) of every CU.  A kernel whose result depends on LDS
 // it never wrote (what a freshly powered GPU hands it: the first process on a box) then produces a different answer after this call.
 __global__ __launch_bounds__(1024) void poison_lds_kernel(uint32_t pattern, int words, uint32_t* sink) {
@@ -1145,82 +1134,6 @@ extern "C" int mmt_debug_poison_lds(uint32_t pattern, void* sink4, mmt_stream_t 
     LAUNCH_CHECK("poison_lds_kernel");
     hipLaunchKernelGGL(poison_vgpr_kernel, dim3(8192), dim3(256), 0, static_cast<hipStream_t>(stream), pattern, static_cast<uint32_t*>(sink4));
     LAUNCH_CHECK("poison_vgpr_kernel");
-    return MMT_OK;
-}
-
-// Test hook: does a workgroup's LDS survive whatever the platform does to a running kernel (queue time-slicing between processes
-// saves and restores waves)?  Each workgroup writes a position-dependent pattern over `bytes` of LDS, idles for `spins` x ~50 us,
-// re-reads it and adds the number of wrong words to *bad (and 1 to bad[1] per workgroup that ran).
-__global__ __launch_bounds__(256) void lds_hold_kernel(int words, int spins, unsigned* bad) {
-    extern __shared__ uint32_t hold_smem[];
-    const uint32_t salt = 0x9E3779B9u * (blockIdx.x + 1);
-    for (int i = threadIdx.x; i < words; i += blockDim.x) hold_smem[i] = salt ^ (uint32_t)i * 2654435761u;
-    __syncthreads();
-    for (int s = 0; s < spins; ++s) { for (int k = 0; k < 1000; ++k) __builtin_amdgcn_s_sleep(127); }   // ~64 x 127 x 1000 cycles
-    __syncthreads();
-    unsigned wrong = 0;
-    for (int i = threadIdx.x; i < words; i += blockDim.x) wrong += (hold_smem[i] != (salt ^ (uint32_t)i * 2654435761u));
-    if (wrong) atomicAdd(bad, wrong);
-    if (threadIdx.x == 0) atomicAdd(bad + 1, 1u);
-}
-// Same question for the vector registers: every lane holds 224 distinct values in VGPRs (made opaque so they are neither
-// recomputed nor reloaded) across the idle time.
-__global__ __launch_bounds__(256, 2) void vgpr_hold_kernel(int spins, unsigned* bad) {
-    constexpr int NR = 224;
-    uint32_t r[NR];
-    const uint32_t salt = 0x85EBCA6Bu * (blockIdx.x * 256 + threadIdx.x + 1);
-#pragma unroll
-    for (int i = 0; i < NR; ++i) { r[i] = salt ^ (uint32_t)(i + 1) * 2654435761u; asm volatile("" : "+v"(r[i])); }
-    const uint32_t mode0 = __builtin_amdgcn_s_getreg((31 << 11) | 1);      // HW_REG_MODE: rounding / denormal / exception bits
-    for (int s = 0; s < spins; ++s) { for (int k = 0; k < 1000; ++k) __builtin_amdgcn_s_sleep(127); }
-    const uint32_t mode1 = __builtin_amdgcn_s_getreg((31 << 11) | 1);
-    unsigned wrong = (mode0 != mode1) ? 1000000u : 0u;                      // a changed MODE register counts a million
-#pragma unroll
-    for (int i = 0; i < NR; ++i) { asm volatile("" : "+v"(r[i])); wrong += (r[i] != (salt ^ (uint32_t)(i + 1) * 2654435761u)); }
-    if (wrong) atomicAdd(bad, wrong);
-    if (threadIdx.x == 0) atomicAdd(bad + 1, 1u);
-}
-// ... and for arithmetic: every lane repeats the operations of the LayerNorm-backward epilogue (IEEE fp32 division, 8-lane
-// butterfly sums through __shfl_xor, fused multiply-adds) on fixed inputs many times and compares each result with the first one.
-__device__ __attribute__((noinline)) float compute_hold_once(float x, float y) {
-    float s1 = x * y, s2 = x - y;
-    s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
-    s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
-    const float sigma = 1.0f / y - 1e-6f;
-    const float k1 = s1 / 128.0f, k2 = s2 / (127.0f * sigma);
-    return y * (x * 1.25f - k1) - k2 * (x - 0.5f) + y;
-}
-__global__ __launch_bounds__(256, 2) void compute_hold_kernel(int iters, unsigned* bad) {
-    float a = 1.0f + 0.001f * (float)(threadIdx.x + 1), b = 3.0f + 0.01f * (float)(blockIdx.x % 97);
-    asm volatile("" : "+v"(a), "+v"(b));
-    const uint32_t ref = __float_as_uint(compute_hold_once(a, b));      // the same out-of-line code every time
-    unsigned wrong = 0;
-    for (int it = 0; it < iters; ++it) {
-        asm volatile("" : "+v"(a), "+v"(b));
-        wrong += (__float_as_uint(compute_hold_once(a, b)) != ref);
-    }
-    if (wrong) atomicAdd(bad, wrong);
-    if (threadIdx.x == 0) atomicAdd(bad + 1, 1u);
-}
-extern "C" int mmt_debug_compute_hold(int iters, int workgroups, void* bad2, mmt_stream_t stream) {
-    if (!bad2) return fail(MMT_EINVAL, "null pointer argument");
-    hipLaunchKernelGGL(compute_hold_kernel, dim3(workgroups), dim3(256), 0, static_cast<hipStream_t>(stream), iters, static_cast<unsigned*>(bad2));
-    LAUNCH_CHECK("compute_hold_kernel");
-    return MMT_OK;
-}
-
-extern "C" int mmt_debug_vgpr_hold(int spins, int workgroups, void* bad2, mmt_stream_t stream) {
-    if (!bad2) return fail(MMT_EINVAL, "null pointer argument");
-    hipLaunchKernelGGL(vgpr_hold_kernel, dim3(workgroups), dim3(256), 0, static_cast<hipStream_t>(stream), spins, static_cast<unsigned*>(bad2));
-    LAUNCH_CHECK("vgpr_hold_kernel");
-    return MMT_OK;
-}
-
-extern "C" int mmt_debug_lds_hold(int bytes, int spins, int workgroups, void* bad2, mmt_stream_t stream) {
-    if (!bad2 || bytes < 4 || bytes > 160 * 1024) return fail(MMT_EINVAL, "bad argument");
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_hold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(lds_hold_kernel, dim3(workgroups), dim3(256), bytes, static_cast<hipStream_t>(stream), bytes / 4, spins, static_cast<unsigned*>(bad2));
-    LAUNCH_CHECK("lds_hold_kernel");
     return MMT_OK;
 }
 

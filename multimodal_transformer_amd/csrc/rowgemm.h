@@ -36,14 +36,6 @@ __device__ unsigned long long* g_phase_buf = nullptr;      // [workgroup][stage 
 #endif
 
 enum { EPI_PLAIN = 0, EPI_FRAG = 1, EPI_LNBWD = 2 };
-// LayerNorm-backward epilogue variant.  1: every operand load of a thread's eight column groups is issued first and kept in
-// registers (96 VGPRs) — about 3 % faster per launch, but its output was not bit-reproducible while another process shared the
-// GPU (tools/hammer_stages.py pins the first differing buffer to this epilogue; the plain variant, 0, is immune
-// in 300 repeats under the same load).  Cause unknown, so the plain variant is the default.
-#ifndef MMT_LNBWD_HOISTED
-#define MMT_LNBWD_HOISTED 0
-#endif
-
 struct RowGemmParams {
     int M, K, KP, N, NP;
     // ---- A operand ----
@@ -519,59 +511,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         float* gr = Gs + row * (NP + 4);
         float mean = 0.f, rstd = 0.f;
         if (m < M) { mean = p.st[2 * (size_t)m]; rstd = p.st[2 * (size_t)m + 1]; }
-        if (MMT_LNBWD_HOISTED && NP <= 256) {
-            // every global load (x, residual gradient, LayerNorm gain) of this thread's <= 8 column groups is issued first
-            constexpr int MAXIT = 8;
-            f32x4 xv[MAXIT], rv[MAXIT], av[MAXIT];
-#pragma unroll
-            for (int it = 0; it < MAXIT; ++it) {
-                const int c = j * 4 + 32 * it;
-                xv[it] = f32x4{0.f, 0.f, 0.f, 0.f}; rv[it] = xv[it]; av[it] = xv[it];
-                if (m < M && c < d) {
-                    xv[it] = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + c);
-                    av[it] = *reinterpret_cast<const f32x4*>(p.ln_a + c);
-                    if (p.dres) rv[it] = *reinterpret_cast<const f32x4*>(p.dres + (size_t)m * p.lddres + c);
-                }
-            }
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int it = 0; it < MAXIT; ++it) {
-                const int c = j * 4 + 32 * it;
-                if (c >= NP) continue;
-                f32x4 gx = {0.f, 0.f, 0.f, 0.f};
-                if (m < M && c < d) {
-                    const f32x4 dy = *reinterpret_cast<const f32x4*>(cr + c);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float xh = (xv[it][i] - mean) * rstd;
-                        const float g = dy[i] * av[it][i];
-                        s1 += g; s2 += g * xh;
-                        gx[i] = dy[i] * xh;
-                        xv[it][i] = xh;                      // keep xhat
-                    }
-                } else {
-                    *reinterpret_cast<f32x4*>(cr + c) = gx;  // zero the pad so the column sums ignore it
-                }
-                *reinterpret_cast<f32x4*>(gr + c) = gx;      // dy * xhat -> d ln_a; Fs keeps dy -> d ln_b
-            }
-            s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
-            s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
-            if (m < M) {
-                const float sigma = 1.0f / rstd - p.eps;
-                const float k1 = s1 / (float)d, k2 = s2 / ((float)(d - 1) * sigma);
-#pragma unroll
-                for (int it = 0; it < MAXIT; ++it) {
-                    const int c = j * 4 + 32 * it;
-                    if (c >= d) continue;
-                    const f32x4 dy = *reinterpret_cast<const f32x4*>(cr + c);
-                    f32x4 o;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = rstd * (dy[i] * av[it][i] - k1) - k2 * xv[it][i] + rv[it][i];
-                    *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + c) = o;
-                    if (KEEP & KEEP_X) *reinterpret_cast<f32x4*>(Xs + row * sm.ldx + c) = o;
-                }
-            }
-        } else {
+        {
         float s1 = 0.f, s2 = 0.f;
         for (int c = j * 4; c < NP; c += 32) {
             f32x4 g = {0.f, 0.f, 0.f, 0.f}, xh = {0.f, 0.f, 0.f, 0.f};

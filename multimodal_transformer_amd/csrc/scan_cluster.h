@@ -10,25 +10,37 @@
 // memset node before each launch (also under hipGraph replay), spins are bounded.
 //
 // Residency: the 4 workgroups of a sequence must run at the same time.  The host only takes this path for
-// 4*B <= 128 workgroups (half the chip), launched as ONE kernel whose block index is decoded so that the four parts of a
-// sequence sit on the same XCD.
+// 4*B <= 128 workgroups and only when the occupancy query says that twice that many fit the device at once (api.hip:
+// cl4_resident), launched as ONE kernel whose block index is decoded so that the four parts of a sequence sit on the same
+// XCD.  Nothing can guarantee residency against other streams or processes holding CUs: every wait is bounded and a
+// time-out raises a device error word (cl_wait_granule) instead of silently consuming a stale granule.
 #pragma once
 #include "scan.h"
 
 #define CL_NP 4                         // workgroups per sequence
 #define CL_UW 64                        // hidden units per workgroup
 #define CL_KP 256                       // padded hidden size
-#define CL_SPIN_MAX (1u << 22)
+#define CL_SPIN_MAX (1u << 20)               // ~1 s of polling before a wait gives up
 
 typedef unsigned long long cl_u64;
 
 __device__ __forceinline__ void cl_store_granule(cl_u64* g, unsigned tag, unsigned value) {
     __hip_atomic_store(g, ((cl_u64)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// one lane polls one granule until its tag matches (bounded)
-__device__ __forceinline__ unsigned cl_wait_granule(cl_u64* g, unsigned tag) {
+// One lane polls one granule until its tag matches.  The spin is bounded: a partner workgroup that is not resident (CUs held by
+// another stream or process) must not hang the kernel.  On exhaustion the lane raises the device error word `err` (surfaced by
+// the callers of mmt_lstm_scan_* at their next synchronisation: the scan's results are then invalid) and stops waiting for the
+// rest of the scan (`dead`), so a failed launch drains in about one time-out instead of T of them.
+__device__ __forceinline__ unsigned cl_wait_granule(cl_u64* g, unsigned tag, unsigned* err, bool& dead) {
     cl_u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (unsigned spins = 0; (unsigned)(x >> 32) != tag && spins < CL_SPIN_MAX; ++spins) {
+    if (dead) return (unsigned)x;
+    unsigned spins = 0;
+    while ((unsigned)(x >> 32) != tag) {
+        if (++spins > CL_SPIN_MAX) {
+            dead = true;
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
         __builtin_amdgcn_s_sleep(1);
         x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -50,7 +62,7 @@ template <int PF>
 __global__ __launch_bounds__(256) void lstm_scan_fwd_cl4_kernel(const float* __restrict__ gx, const bf16* __restrict__ Wf,
                                                                 const float* __restrict__ h0, const float* __restrict__ c0,
                                                                 float* __restrict__ h_all, float* __restrict__ c_all,
-                                                                float* __restrict__ acts, cl_u64* xb, int T, int B, int H, int HP16) {
+                                                                float* __restrict__ acts, cl_u64* xb, unsigned* err, int T, int B, int H, int HP16) {
     constexpr int KS = CL_KP / 32, LDH = CL_KP + 8;
     __shared__ __attribute__((aligned(16))) bf16 hbuf[2 * LDH];            // the sequence's h, bf16, double buffered
     __shared__ __attribute__((aligned(16))) float gslot[2 * 4 * CL_UW];    // [slot][gate][own unit]
@@ -97,6 +109,7 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_cl4_kernel(const float* __r
     cl_u64* xseq = xb + (size_t)b * 2 * CL_NP * 32;
     float* xw = xch + w * 64;
     int cur = 0;
+    bool dead = false;
     auto step = [&](int t, f32x4& in) {
         float gin[4];
         const float* sl = gslot + (t & 1) * 4 * CL_UW + 16 * w + du;
@@ -133,7 +146,7 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_cl4_kernel(const float* __r
         }
         if (tid < 96) {
             const int sp = (part + 1 + (tid >> 5)) & 3, g = tid & 31;
-            const unsigned v = cl_wait_granule(xseq + ((t & 1) * CL_NP + sp) * 32 + g, (unsigned)(t + 1));
+            const unsigned v = cl_wait_granule(xseq + ((t & 1) * CL_NP + sp) * 32 + g, (unsigned)(t + 1), err, dead);
             *reinterpret_cast<unsigned*>(hbuf + (cur ^ 1) * LDH + CL_UW * sp + 2 * g) = v;
         }
         lds_barrier();
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_cl4_kernel(const float* __r
                                                                 const bf16* __restrict__ Wb, const float* __restrict__ c0,
                                                                 const float* __restrict__ c_all, const float* __restrict__ acts,
                                                                 float* __restrict__ dG, float* __restrict__ dh0, float* __restrict__ dc0,
-                                                                cl_u64* xb, int T, int B, int H, int HP16) {
+                                                                cl_u64* xb, unsigned* err, int T, int B, int H, int HP16) {
     constexpr int KP4 = 4 * CL_KP, KS4 = KP4 / 32, LDG = KP4 + 8;
     __shared__ __attribute__((aligned(16))) bf16 gbuf[2 * LDG];            // the sequence's gate gradients, k = gate*256 + unit
     __shared__ __attribute__((aligned(16))) float gslot[2 * 8 * CL_UW];    // [slot][segment][own unit]
@@ -219,6 +232,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_cl4_kernel(const float* __r
     cl_u64* xseq = xb + (size_t)b * 2 * CL_NP * 128;
     float* xw = xch + w * 16;
     int cur = 0;
+    bool dead = false;
     float dhd = 0.f, dcd = 0.f;
     auto step = [&](int t, f32x4& cslot) {
         const int it = T - 1 - t;
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_cl4_kernel(const float* __r
             const int i = tid + 256 * rnd;                                 // 384 granules to collect
             if (i < 384) {
                 const int sp = (part + 1 + (i >> 7)) & 3, g = i & 127, q = g >> 5, u2 = g & 31;
-                const unsigned v = cl_wait_granule(xseq + ((it & 1) * CL_NP + sp) * 128 + g, (unsigned)(it + 1));
+                const unsigned v = cl_wait_granule(xseq + ((it & 1) * CL_NP + sp) * 128 + g, (unsigned)(it + 1), err, dead);
                 *reinterpret_cast<unsigned*>(gw + q * CL_KP + CL_UW * sp + 2 * u2) = v;
             }
         }

@@ -31,7 +31,7 @@ class _EncoderStackFn(torch.autograd.Function):
         nbytes = lib.mmt_encoder_workspace_bytes(B, T, d, h, d_ff, n_layers)
         if nbytes == 0:
             _lib.check(lib.mmt_encoder_forward(None, None, None, None, None, 0, B, T, d, h, d_ff, n_layers, eps, 0.0, 0, None))
-        ws = _lib.POOL.get(nbytes, x_.device)
+        ws = _lib.POOL.get(nbytes, x_.device, tag=("encoder", B, T, d, h, d_ff, n_layers))
         y = torch.empty_like(x_)
         _lib.check(lib.mmt_encoder_forward(_lib.ptr(x_), _lib.ptr(m_), _lib.ptr(p_), _lib.ptr(y), _lib.ptr(ws), nbytes,
                                            B, T, d, h, d_ff, n_layers, eps, dropout_p, seed, _lib.stream_ptr()))
@@ -155,7 +155,7 @@ class _SdpaFn(torch.autograd.Function):
         nbytes = lib.mmt_sdpa_workspace_bytes(B, T, d, h)
         if nbytes == 0:
             _lib.check(lib.mmt_sdpa_forward(None, None, None, None, None, None, 0, B, T, d, h, None))
-        ws = _lib.POOL.get(nbytes, q_.device)
+        ws = _lib.POOL.get(nbytes, q_.device, tag=("sdpa", B, T, d, h))
         out = torch.empty_like(q_)
         _lib.check(lib.mmt_sdpa_forward(_lib.ptr(q_), _lib.ptr(k_), _lib.ptr(v_), _lib.ptr(m_), _lib.ptr(out), _lib.ptr(ws), nbytes,
                                         B, T, d, h, _lib.stream_ptr()))
@@ -254,6 +254,8 @@ class _LstmScanFn(torch.autograd.Function):
         acts = torch.empty(T, B, 4 * H, dtype=torch.float32, device=gx_.device)
         _lib.check(lib.mmt_lstm_scan_forward(_lib.ptr(gx_), _lib.ptr(W_), _lib.ptr(h0_), _lib.ptr(c0_), _lib.ptr(h_all), _lib.ptr(c_all),
                                              _lib.ptr(acts), _lib.ptr(ws), nbytes, T, B, H, _lib.stream_ptr()))
+        if H > 128:                                 # four-CU scan: its exchange waits are bounded and report through this word
+            _lib.ERRORS.watch(ws[:4].view(torch.int32), "lstm_scan forward (T=%d, B=%d, H=%d)" % (T, B, H))
         ctx.save_for_backward(W_, h0_, c0_, h_all, c_all, acts)
         ctx.dims = (T, B, H, nbytes)
         return h_all, c_all
@@ -271,6 +273,8 @@ class _LstmScanFn(torch.autograd.Function):
         dc0 = torch.empty(B, H, dtype=torch.float32, device=dev)
         _lib.check(lib.mmt_lstm_scan_backward(_lib.ptr(dh_), _lib.ptr(dc_), _lib.ptr(W_), _lib.ptr(c0_), _lib.ptr(c_all), _lib.ptr(acts),
                                               _lib.ptr(dgx), _lib.ptr(dh0), _lib.ptr(dc0), _lib.ptr(ws), nbytes, T, B, H, _lib.stream_ptr()))
+        if H > 128:
+            _lib.ERRORS.watch(ws[:4].view(torch.int32), "lstm_scan backward (T=%d, B=%d, H=%d)" % (T, B, H))
         dW = None
         if ctx.needs_input_grad[1]:
             # dW_rec = sum_{t,b} dG[t,b,:]^T h_{t-1}[b,:]  — a window-contraction: the weight-gradient GEMM
@@ -406,6 +410,11 @@ class _MfnMemScanFn(torch.autograd.Function):
 
 def mfn_mem_scan(apre, chat, Wm, W2, b2, dropout_p=0.0, seed=0):
     return _MfnMemScanFn.apply(apre, chat, Wm, W2, b2, float(dropout_p), int(seed))
+
+
+def check_device_errors():
+    """Synchronise and raise if an asynchronous kernel reported an error through its device error word (mmt_hip.h)."""
+    _lib.ERRORS.check()
 
 
 def poison_lds(device, pattern=0x7FC00000):

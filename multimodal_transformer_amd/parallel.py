@@ -52,9 +52,12 @@ def gradient_buckets(params):
     return bases, loose
 
 
-def allreduce_gradients(params, group=None):
-    """SUM all-reduce of every gradient, in place.  Returns the number of collectives issued."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def allreduce_gradients(params, group=None, force=False):
+    """SUM all-reduce of every gradient, in place.  Returns the number of collectives issued.
+    A world of one rank needs no exchange and issues none, unless ``force`` (used to exercise the collective path itself)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    if dist.get_world_size(group) == 1 and not force:
         return 0
     bases, loose = gradient_buckets(list(params))
     n = 0

@@ -181,11 +181,8 @@ def test_results_do_not_depend_on_unwritten_lds(dev, d, h, B, T, p):
 
     ref = run()
     for pattern in (0x7FC00000, 0xFFFFFFFF):
-        for attempt in range(3):            # retried: with the GPU shared by another process runs can differ by a rounding
-            F.poison_lds(dev, pattern)
-            cur = run()
-            if all(torch.equal(a, b) for a, b in zip(ref, cur)):
-                break
+        F.poison_lds(dev, pattern)
+        cur = run()
         for name, a, b in zip(("y", "dx", "dparams"), ref, cur):
             assert torch.isfinite(b).all(), "%s not finite after LDS was filled with %08x" % (name, pattern)
             assert torch.equal(a, b), "%s changed after LDS was filled with %08x" % (name, pattern)

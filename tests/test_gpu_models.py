@@ -43,7 +43,9 @@ def _oracle_lstm(gx, W, h0, c0):
                                         # > 256 sequences: 2 per workgroup; > 512: 4+ per workgroup and the per-lane loader
                                         (6, 300, 88, True), (5, 601, 48, True), (4, 1100, 128, False),
                                         # hidden sizes above 128: four workgroups per sequence up to 32 sequences, one beyond
-                                        (40, 32, 256, True), (7, 3, 200, True), (5, 1, 132, False), (6, 40, 256, True), (3, 300, 160, False)])
+                                        (40, 32, 256, True), (7, 3, 200, True), (5, 1, 132, False), (6, 40, 256, True), (3, 300, 160, False),
+                                        # T = 1000 (configs[4]): the MFN cell sizes and the reference-default decoder size
+                                        (1000, 2, 88, False), (1000, 3, 48, True), (1000, 2, 256, True)])
 def test_lstm_scan(dev, T, B, H, init):
     tag = "lstm%d_%d_%d" % (T, B, H)
     gx = R.gen_normal(tag + "gx", (T, B, 4 * H), 13)
@@ -63,6 +65,7 @@ def test_lstm_scan(dev, T, B, H, init):
     for name, a, b in zip(("dgx", "dW", "dh0", "dc0"), gl, leaves):
         if a is not None:
             assert _report(tag + " " + name, a.grad.cpu(), b.grad) < GRAD_RTOL, name
+    F.check_device_errors()                 # the four-CU scans' exchange time-out word must be zero
 
 
 def _oracle_mem_scan(apre, chat, Wm, W2, b2):
@@ -79,7 +82,7 @@ def _oracle_mem_scan(apre, chat, Wm, W2, b2):
     return torch.stack(out)
 
 
-@pytest.mark.parametrize("T,B", [(20, 3), (1, 1), (33, 18), (5, 300), (3, 1030)])
+@pytest.mark.parametrize("T,B", [(20, 3), (1, 1), (33, 18), (5, 300), (3, 1030), (1000, 2)])
 def test_mfn_mem_scan(dev, T, B):
     tag = "mem%d_%d" % (T, B)
     apre = R.gen_normal(tag + "a", (T, B, 128), 17)
