@@ -21,7 +21,11 @@ Primary workload (`value`): the encoder-stack hot path of the SFT configuration 
                  front-end, fusion, NLPTransformer) with the raw fp32 windows resident in HBM; conv_fwd = the
                  MFMA fraction of the window-encoder kernel;
   mft_model    — (N=1) the whole MFT model of configs[2] (3 modality encoders + MFN gate, T=300).
-`roofline.traffic` is read from profiles/r01_pmc_per_kernel.json (separate rocprofv3 --pmc passes of this workload).
+  config_full_batch — (N=1) configs[3] at its full batch of 256 sequences on ONE GPU (the 32-sequence slice above is the
+                 weak-scaling anchor; the batch also fits one GPU);
+  mft_configs4 — (N=1) the whole MFT model at the configs[4] per-GPU slice (3 modalities, T=1000, 64 sequences, d=256).
+`roofline.traffic` comes from profiles/r*_pmc_per_kernel.json (separate rocprofv3 --pmc passes of this workload) and only if
+that summary was collected on the kernel sources now running (sha of csrc/); otherwise it is null with the reason.
 """
 import argparse
 import json
@@ -85,26 +89,48 @@ SITE_KERNELS = {          # launch site -> kernel symbol prefix in the rocprofv3
 }
 
 
+def kernel_source_sha():
+    """sha256 over the kernel sources (csrc/*.h, api.hip): identifies the code a counter summary was collected on.
+    (The GPU box has no .git, so the git head cannot serve; tools/summarize_profiles.py records the same hash.)"""
+    import hashlib
+    csrc = os.path.join(ROOT, "multimodal_transformer_amd", "csrc")
+    hsh = hashlib.sha256()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".h", ".hip")):
+            with open(os.path.join(csrc, name), "rb") as fh:
+                hsh.update(name.encode() + b"\0" + fh.read())
+    return hsh.hexdigest()[:16]
+
+
 def pmc_traffic(site, train, cfg):
-    """HBM-side bytes per launch of the site's kernel from the committed rocprofv3 counter summary (separate --pmc passes of
+    """HBM-side bytes per launch of the site's kernel from a committed rocprofv3 counter summary (separate --pmc passes of
     this same workload; FETCH_SIZE x2 + WRITE_SIZE, KiB units — MI355X_MICROARCH.md 'HBM').  bench.py cannot run the
-    profiler around itself, so the figure is read from profiles/; None if the workload differs or the file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_per_kernel.json")
-    if not os.path.exists(path) or site not in SITE_KERNELS:
-        return None, None
-    try:
-        with open(path) as fh:
-            tab = json.load(fh)
-    except (OSError, ValueError):
-        return None, None
-    meta = tab.get("_meta", {})
-    if meta.get("workload") != cfg["desc"] or bool(meta.get("train")) != bool(train):
-        return None, None
-    pref = SITE_KERNELS[site]
-    for k, v in tab.items():
-        if k.startswith(pref) and "hbm_bytes_per_launch" in v:
-            return int(v["hbm_bytes_per_launch"]), "profiles/r01_pmc_per_kernel.json (%s)" % k
-    return None, None
+    profiler around itself, so the figure is read from profiles/ — and ONLY from a summary collected on exactly the kernel
+    sources that are running now (`_meta.csrc_sha`), for this workload and mode; otherwise traffic is null and the reason is
+    given instead of a stale number."""
+    import glob
+    if site not in SITE_KERNELS:
+        return None, "no counter mapping for this launch site"
+    sha, why = kernel_source_sha(), "no profiles/r*_pmc_per_kernel.json"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_kernel.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                tab = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        meta, rel = tab.get("_meta", {}), os.path.relpath(path, ROOT)
+        if meta.get("csrc_sha") != sha:
+            why = "stale: %s was collected on kernel sources %s, running %s" % (rel, meta.get("csrc_sha"), sha)
+            continue
+        if meta.get("workload") != cfg["desc"] or bool(meta.get("train")) != bool(train):
+            why = "%s is for another workload / mode" % rel
+            continue
+        pref = SITE_KERNELS[site]
+        for k, v in tab.items():
+            if k.startswith(pref) and "hbm_bytes_per_launch" in v:
+                return int(v["hbm_bytes_per_launch"]), "%s (%s)" % (rel, k)
+        why = "%s has no entry for %s" % (rel, pref)
+    return None, why
 
 
 def make_encoder(cfg):
@@ -200,6 +226,24 @@ class Runner:
         else:
             self.eager()
 
+    def allreduce_ms(self, steps):
+        """mean device time of the gradient exchange alone (HIP events on the launch stream), outside the timed region"""
+        if self.world == 1:
+            return None
+        tot = 0.0
+        for _ in range(steps):
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self.fwd_bwd()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self.parallel.allreduce_gradients(self.params)
+            b.record()
+            b.synchronize()
+            tot += a.elapsed_time(b)
+        return tot / steps
+
     def timed(self, steps, dist=None, dev=None):
         if self.world > 1:
             dist.barrier()
@@ -280,6 +324,7 @@ def main():
     elapsed = run.timed(args.steps, dist, dev)
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * M * args.steps / elapsed
+    ar_ms = run.allreduce_ms(max(5, args.steps // 2))
 
     # ---- the same step followed by the reference's optimiser (Adam lr 1e-4, weight decay 1e-4: transformer/SFT/train.py:621);
     #      reported beside the headline, never as it ("with and without Adam + all-reduce")
@@ -434,6 +479,68 @@ def main():
                         "on concurrent streams + MFN gate; T=300, 32 sequences (configs[2])",
                "value": round(Bm * Tm * nst2 / el2, 1), "unit": "windows/s", "ms_per_step": round(1e3 * el2 / nst2, 4), "launch": mrun2.launch}
 
+    # ---- configs[3] at its full batch (256 sequences) on one GPU
+    full_batch = None
+    if rank == 0 and world == 1 and not args.no_full_model and args.workload == "C4" and args.batch == 0:
+        Bf = 256
+        xf = torch.randn(Bf, T, d, generator=g).to(dev).requires_grad_()
+        tgtf = torch.rand(Bf, T, d, generator=g).to(dev)
+        maskf = torch.ones(Bf, T, 1, device=dev)
+
+        def full_step():
+            for p in params:
+                p.grad = None
+            xf.grad = None
+            (((enc(xf, maskf) - tgtf) ** 2).sum() / float(Bf * T)).backward()
+
+        frun = Runner(full_step, params, 1, not args.no_graph, 2)
+        nf = max(5, args.steps // 2)
+        elf = frun.timed(nf)
+        vf = Bf * T * nf / elf
+        full_batch = {"workload": "SFT encoder stack T=500 d_model=128 heads=8 N=6 d_ff=128, 256 sequences on ONE GPU (configs[3] whole batch)",
+                      "value": round(vf, 1), "unit": "windows/s", "ms_per_step": round(1e3 * elf / nf, 4), "launch": frun.launch,
+                      "step_mfma_frac": round(vf * 3 * N * flops_per_window_layer_fwd(d, T, f) / (MFMA_BF16_PEAK_TFLOPS * 1e12), 5)}
+        del xf, tgtf, frun
+        torch.cuda.empty_cache()
+
+    # ---- whole MFT model at the configs[4] per-GPU slice (3 modalities, T=1000, 64 sequences, d=256), N=1 only
+    mft4 = None
+    if rank == 0 and world == 1 and not args.no_full_model and args.workload == "C4":
+        from multimodal_transformer_amd import multiTransformer as MT
+        torch.manual_seed(1)
+        mods = ["acoustic", "image", "linguistic"]
+        dims = {"acoustic": 88, "image": 256, "linguistic": 300}
+        B4, T4 = 64, 1000
+        m4 = MT.MultiTransformer(mods, dims, device=dev)
+        m4.train(train)
+        p4 = list(m4.parameters())
+        x4 = {m: torch.randn(B4, T4, dims[m], generator=g).to(dev) for m in mods}
+        mask4 = torch.ones(B4, T4, 1, device=dev)
+        tgt4 = torch.rand(B4, T4, 1, generator=g).to(dev)
+
+        def mft4_step():
+            for p in p4:
+                p.grad = None
+            (((m4(x4, mask4, [T4] * B4) - tgt4) ** 2).sum() / float(B4 * T4)).backward()
+
+        n4 = 5
+        r4 = Runner(mft4_step, p4, 1, not args.no_graph, 2)
+        el4 = r4.timed(n4)
+        if r4.launch == "hipgraph":
+            r4e = Runner(mft4_step, p4, 1, False, 1)
+            el4e = r4e.timed(n4)
+            if el4e < el4:
+                el4, r4 = el4e, r4e
+        v4 = B4 * T4 * n4 / el4
+        fpw4 = 3 * 3 * 6 * flops_per_window_layer_fwd(256, T4, 128) + 3 * 1.35e6          # three stacks + MFN gate
+        mft4 = {"model": "MultiTransformer(acoustic 88, image 256, linguistic 300 -> 256): 3 embeds + 3 encoder stacks (d=256, h=8, N=6) + "
+                         "MFN gate; T=1000, 64 sequences (configs[4] per-GPU slice)",
+                "value": round(v4, 1), "unit": "windows/s", "ms_per_step": round(1e3 * el4 / n4, 4), "launch": r4.launch,
+                "algorithmic_mflop_per_window": round(fpw4 / 1e6, 2),
+                "step_mfma_frac": round(v4 * fpw4 / (MFMA_BF16_PEAK_TFLOPS * 1e12), 5)}
+        del x4, m4, r4
+        torch.cuda.empty_cache()
+
     if rank == 0:
         fpw = 3 * N * flops_per_window_layer_fwd(d, T, f)
         out = {
@@ -453,8 +560,15 @@ def main():
             "roofline": roofline,
             "kernel_ms_per_step": kernel_ms,
         }
+        if ar_ms is not None:
+            out["allreduce_ms"] = round(ar_ms, 4)
+            out["allreduce_what"] = "mean device time of the gradient SUM all-reduce alone (HIP events around it, after the graph replay)"
         if adam is not None:
             out["with_adam"] = adam
+        if full_batch is not None:
+            out["config_full_batch"] = full_batch
+        if mft4 is not None:
+            out["mft_configs4"] = mft4
         if full is not None:
             out["full_model"] = full
         if pipeline is not None:

@@ -86,12 +86,17 @@ int mmt_layernorm_backward(const float* dy, const float* x, const float* a_2, co
 /* ---- Scaled dot-product attention core on already-projected q, k, v.
  * Replaces attention(query, key, value, mask)                 transformer/MFT/multiTransformer.py:22-34
  * q,k,v,ctx: (B,T,d) fp32 with head `i` in columns [i*d/h,(i+1)*d/h) (the layout before the reference's
- * .view(B,-1,h,d_k).transpose(1,2)); mask (B,T,1) blanks QUERY rows; may be NULL. */
+ * .view(B,-1,h,d_k).transpose(1,2)); mask (B,T,1) blanks QUERY rows; may be NULL.
+ * dropout_p, seed: the reference's nn.Dropout on p_attn (:32-33) in train mode (0 = eval / dropout=None); the decisions are
+ * drawn by the forward into the workspace and re-read by the backward (same dropout_p and seed must be passed); they are
+ * dropout stream 0 of mmt_debug_dropout_mask. */
 size_t mmt_sdpa_workspace_bytes(int B, int T, int d, int h);
 int mmt_sdpa_forward(const float* q, const float* k, const float* v, const float* mask, float* ctx,
-                     void* workspace, size_t workspace_bytes, int B, int T, int d, int h, mmt_stream_t stream);
+                     void* workspace, size_t workspace_bytes, int B, int T, int d, int h,
+                     float dropout_p, uint64_t seed, mmt_stream_t stream);
 int mmt_sdpa_backward(const float* dctx, const float* mask, float* dq, float* dk, float* dv,
-                      void* workspace, size_t workspace_bytes, int B, int T, int d, int h, mmt_stream_t stream);
+                      void* workspace, size_t workspace_bytes, int B, int T, int d, int h,
+                      float dropout_p, uint64_t seed, mmt_stream_t stream);
 
 /* ---- Fused affine map  y = act(x W^T + b) [* rowscale] on bf16 MFMA.
  * Replaces nn.Linear (+ F.relu) call sites of the path: PositionwiseFeedForward (:15-20), the four
@@ -159,8 +164,8 @@ int mmt_convpool_backward(const float* x, const float* dout, const int32_t* argm
 
 /* ---- Test hook: the keep-mask (1 = kept) of dropout stream `stream_id` for indices [0,n) under (p, seed), and the
  * scale applied to kept values (host pointer, may be NULL).  Streams used by the encoder stack for layer l:
- * 4l+0 attention probabilities, index ((b*h+head)*Tp + q)*Tp + key (Tp = T rounded up to 32; pass attn_Tp = Tp,
- *      0 for every other stream);
+ * 4l+0 attention probabilities, index ((b*h+head)*Tp + q)*Tp + key (Tp = T rounded up to 32; pass attn_Tp = Tp and
+ *      n = B*h*Tp*Tp; 0 for every other stream).  These are stored bit masks drawn once per forward (csrc/attn_mask.h);
  * 4l+1 / 4l+3 sublayer outputs and 4l+2 FFN hidden, index m*NP + n (NP = width rounded up to 64);
  * 1000: MFN gamma hidden, index (t*B+b)*128 + j. */
 int mmt_debug_dropout_mask(float p, uint64_t seed, uint32_t stream_id, uint64_t n, uint32_t attn_Tp, uint8_t* keep,

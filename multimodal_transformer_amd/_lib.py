@@ -10,7 +10,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmt_hip.so")
+LIB_PATH = os.environ.get("MMT_LIB_PATH") or os.path.join(_HERE, "libmmt_hip.so")     # MMT_LIB_PATH: developer builds (tools/)
 
 _c = ctypes
 _P, _F, _I, _SZ, _U64 = _c.c_void_p, _c.c_float, _c.c_int, _c.c_size_t, _c.c_uint64
@@ -32,8 +32,8 @@ SIGNATURES = {
     "mmt_layernorm_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "mmt_layernorm_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "mmt_sdpa_workspace_bytes": (_SZ, [_I] * 4),
-    "mmt_sdpa_forward": (_I, [_P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_P]),
-    "mmt_sdpa_backward": (_I, [_P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_P]),
+    "mmt_sdpa_forward": (_I, [_P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_F, _U64, _P]),
+    "mmt_sdpa_backward": (_I, [_P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_F, _U64, _P]),
     "mmt_linear_workspace_bytes": (_SZ, [_I] * 3),
     "mmt_linear_forward": (_I, [_P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_P]),
     "mmt_linear_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_P]),
@@ -154,25 +154,34 @@ class DeviceErrorWatch:
     """Device error words of asynchronous kernels (today: the exchange time-out of the four-CU LSTM scans,
     include/mmt_hip.h mmt_lstm_scan_*).  ``watch`` copies the word to pinned host memory behind the launch and records an
     event; ``poll`` (called at every later launch, never blocking) and ``check`` (blocking) raise if a drained launch left
-    a non-zero word.  Inside a hipGraph capture the copy becomes a node of the graph: every replay refreshes the host word,
-    which ``check`` reads after the caller's synchronisation."""
+    a non-zero word.  Launches captured into a hipGraph are not watched (no host bookkeeping inside a capture)."""
+
+    SLOTS = 2048                    # ring of pinned host words
 
     def __init__(self):
-        self._pending = []          # (host word, event or None, description)
-        self._captured = []
+        self._pending = []          # (host word, event, description)
         self._mutex = threading.Lock()
+        self._host = None
+        self._next = 0
 
     def watch(self, dev_word, what):
-        host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        host.copy_(dev_word, non_blocking=True)
-        capturing = torch.cuda.is_current_stream_capturing()
-        ev = None
-        if not capturing:
-            ev = torch.cuda.Event()
-            ev.record()
+        if torch.cuda.is_current_stream_capturing():
+            return                  # no host-side bookkeeping inside a capture: the word still sits at offset 0 of the workspace
         with self._mutex:
-            (self._captured if capturing else self._pending).append((host, ev, what))
-        self.poll()
+            if self._host is None:
+                self._host = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
+            i, self._next = self._next, (self._next + 1) % self.SLOTS
+            host = self._host[i:i + 1]
+            overflow = len(self._pending) > self.SLOTS - 64     # never let the ring lap an unchecked entry
+        host.copy_(dev_word, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        with self._mutex:
+            self._pending.append((host, ev, what))
+        if overflow:
+            self.check()
+        else:
+            self.poll()
 
     @staticmethod
     def _raise(what):
@@ -193,7 +202,7 @@ class DeviceErrorWatch:
         """Synchronise the device and raise if any watched launch (eager or replayed from a graph) reported an error."""
         torch.cuda.synchronize()
         with self._mutex:
-            entries, self._pending = self._pending + self._captured, []
+            entries, self._pending = self._pending, []
         for host, _, what in entries:
             if int(host[0]) != 0:
                 self._raise(what)

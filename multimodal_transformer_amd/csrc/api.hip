@@ -11,6 +11,7 @@
 #include "../../include/mmt_hip.h"
 #include "common.h"
 #include "rowgemm.h"
+#include "attn_mask.h"
 #include "attn.h"
 #include "attn_bwd_fused.h"
 #include "misc_kernels.h"
@@ -35,7 +36,7 @@ static int fail(int code, const char* fmt, ...) {
 // dominant kernel's average duration on the stream the kernels really run on.
 enum Site { S_PREP = 0, S_LN1_QKV, S_ATTN_FWD, S_OUTPROJ, S_LN2_FFN1, S_FFN2, S_LN_FWD, S_LN_BWD, S_BWD_FFN2, S_BWD_FFN1_LN2,
             S_BWD_OUTPROJ, S_ATTN_BWD, S_ATTN_BWD_DQ, S_BWD_QKV_LN1, S_WGRAD, S_FINALIZE, S_OTHER,
-            S_LINEAR_FWD, S_LINEAR_BWD_DX, S_LINEAR_WGRAD, S_LSTM_FWD, S_LSTM_BWD, S_MEM_FWD, S_MEM_BWD, S_CONV_FWD, S_CONV_BWD, S_CHAIN4_FWD, S_ATTN_BWD_FUSED, S_COUNT };
+            S_LINEAR_FWD, S_LINEAR_BWD_DX, S_LINEAR_WGRAD, S_LSTM_FWD, S_LSTM_BWD, S_MEM_FWD, S_MEM_BWD, S_CONV_FWD, S_CONV_BWD, S_CHAIN4_FWD, S_ATTN_BWD_FUSED, S_MASK_GEN, S_COUNT };
 static const char* const g_site_names[S_COUNT] = {
     "encoder_prep_kernel", "rowgemm<FRAG,LN>:ln1+qkv", "attn_fwd_kernel", "chain:outproj+res>ln2+ffn1>ffn2+res",
     "rowgemm<PLAIN,LN>:ln2+ffn1+relu", "rowgemm<PLAIN>:ffn2+res", "layernorm_fwd_kernel", "layernorm_bwd_kernel",
@@ -43,7 +44,7 @@ static const char* const g_site_names[S_COUNT] = {
     "attn_bwd_dq_kernel", "rowgemm<LNBWD>:bwd_qkv+ln1", "wgrad_kernel", "finalize_kernels", "other",
     "rowgemm<PLAIN>:linear_fwd", "rowgemm<PLAIN>:linear_bwd_dx", "wgrad_kernel:linear", "lstm_scan_fwd_kernel", "lstm_scan_bwd_kernel",
     "mfn_mem_scan_fwd_kernel", "mfn_mem_scan_bwd_kernel", "convpool_fwd_kernel", "convpool_bwd_kernel",
-    "chain:outproj+res>ln2+ffn1>ffn2+res>ln1+qkv(next)", "attn_bwd_fused16_kernel"};
+    "chain:outproj+res>ln2+ffn1>ffn2+res>ln1+qkv(next)", "attn_bwd_fused16_kernel", "attn_mask_gen_kernel"};
 struct ProfRec { int site; hipEvent_t a, b; };
 static bool g_prof = false;
 static ProfRec* g_recs = nullptr;
@@ -141,6 +142,7 @@ struct LayerWs {
     // backward operands of the weight-gradient GEMMs, kept per layer so ONE batched launch forms every layer's dW
     bf16 *dx2T, *dhT, *dx1T, *dqkvT;
     float *lnpart1, *lnpart2;
+    uint32_t *maskQ, *maskK;                // attention-dropout lane masks of this layer (attn_mask.h)
 };
 struct EncWs {
     bf16* wprep; float* bprep; float* statsf;
@@ -174,6 +176,12 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
         w.hid = c.take<bf16>(M * L.FP); w.hidT = c.take<bf16>((size_t)L.FP * MP);
         w.dx2T = c.take<bf16>((size_t)L.DP * MP); w.dhT = c.take<bf16>((size_t)L.FP * MP);
         w.dx1T = c.take<bf16>((size_t)L.DP * MP); w.dqkvT = c.take<bf16>((size_t)L.NQ * MP);
+    }
+    {   // attention-dropout bit masks: [layer][bh][tile][tile][32 words], both orientations, written by ONE generator launch
+        const size_t lw = attn_mask_layer_words(D.B * D.h, D.nt);
+        uint32_t* mq = c.take<uint32_t>(lw * (size_t)(D.N > 0 ? D.N : 1));
+        uint32_t* mk = c.take<uint32_t>(lw * (size_t)(D.N > 0 ? D.N : 1));
+        for (int l = 0; l < D.N; ++l) { W.lw[l].maskQ = mq ? mq + lw * l : nullptr; W.lw[l].maskK = mk ? mk + lw * l : nullptr; }
     }
     for (int l = 0; l < D.N; ++l) {        // contiguous [layer][2 norms][G][2][DP] so one launch reduces them all
         W.lw[l].lnpart1 = c.take<float>((size_t)D.G * 2 * L.DP); W.lw[l].lnpart2 = c.take<float>((size_t)D.G * 2 * L.DP);
@@ -250,12 +258,38 @@ static RowGemmParams rg_zero() { RowGemmParams p; memset(&p, 0, sizeof(p)); p.ma
 
 static DropCfg no_drop() { return make_drop(0.f, 0, 0); }
 
+// Attention-probability dropout of `nlayers` layers: ONE launch draws every decision (stream 4l+0 of layer l) into the lane-mask
+// arrays mq / mk (layer l at + l * attn_mask_layer_words).  attn_mask.h.
+static int launch_mask_gen(uint32_t* mq, uint32_t* mk, const EncDims& D, int nlayers, float p, uint64_t seed, hipStream_t st) {
+    if (nlayers > 16) return fail(MMT_EUNSUPPORTED, "mask generator: %d layers > 16", nlayers);
+    MaskGenParams P; memset(&P, 0, sizeof(P));
+    P.mq = mq; P.mk = mk; P.nbh = D.B * D.h; P.nt = D.nt; P.nlayers = nlayers;
+    P.layer_words = attn_mask_layer_words(P.nbh, P.nt);
+    for (int l = 0; l < nlayers; ++l) { const DropCfg c = make_drop(p, seed, 4 * l + 0); P.thr16 = c.thr16; P.s0[l] = c.s0; P.s1[l] = c.s1; }
+    const size_t blocks = (size_t)P.nbh * P.nt * P.nt;
+    ProfScope prof(S_MASK_GEN, st);
+    hipLaunchKernelGGL(attn_mask_gen_kernel, dim3((unsigned)((blocks + 255) / 256), nlayers), dim3(256), 0, st, P);
+    LAUNCH_CHECK("attn_mask_gen_kernel");
+    return MMT_OK;
+}
+
+// `drop`: the layer's attention dropout (thr16 == 0: off); maskQ: its lane masks, written by launch_mask_gen
 static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* VT, bf16* ctx, bf16* ctxT, float* lse,
-                           const EncDims& D, hipStream_t st, DropCfg drop = no_drop()) {
+                           const EncDims& D, hipStream_t st, DropCfg drop = no_drop(), const uint32_t* maskQ = nullptr) {
     dim3 grid(attn_grid((D.nt + 3) / 4, D.B * D.h));
+    if (drop.thr16 && !maskQ) return fail(MMT_EINVAL, "attention dropout without a mask buffer");
     ProfScope prof(S_ATTN_FWD, st);
 #define MMT_FWD(dkp, dr) hipLaunchKernelGGL((attn_fwd_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, \
-                                            D.h, D.T, D.nt, D.B * D.h, D.L.HDP, D.MP, drop)
+                                            D.h, D.T, D.nt, D.B * D.h, D.L.HDP, D.MP, maskQ, drop.scale)
+#ifdef MMT_ABLATIONS
+    static const int abl = getenv("MMT_ABL") ? atoi(getenv("MMT_ABL")) : 0;
+#define MMT_FWD_A(a) hipLaunchKernelGGL((attn_fwd_kernel<16, true, a>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, \
+                                        D.h, D.T, D.nt, D.B * D.h, D.L.HDP, D.MP, maskQ, drop.scale)
+    if (abl && DKP == 16 && drop.thr16) {
+        switch (abl) { case 1: MMT_FWD_A(1); break; case 2: MMT_FWD_A(2); break; case 3: MMT_FWD_A(3); break; case 4: MMT_FWD_A(4); break; default: MMT_FWD_A(5); }
+        LAUNCH_CHECK("attn_fwd_kernel"); return MMT_OK;
+    }
+#endif
     if (DKP == 16) { if (drop.thr16) MMT_FWD(16, true); else MMT_FWD(16, false); }
     else { if (drop.thr16) MMT_FWD(32, true); else MMT_FWD(32, false); }
 #undef MMT_FWD
@@ -266,9 +300,11 @@ static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* 
 // dQ, dK, dV -> bf16 row-major dqkv [M][NQ] (columns: dQ | dK | dV, heads padded) and its T layout [NQ][MP]
 static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* KR, const bf16* KT_, const bf16* VR,
                            const bf16* dOR, const bf16* dOT, const float* lse, const float* delta, const float* rowmask,
-                           bf16* dqkv, bf16* dqkvT, const EncDims& D, hipStream_t st, DropCfg drop = no_drop()) {
+                           bf16* dqkv, bf16* dqkvT, const EncDims& D, hipStream_t st, DropCfg drop = no_drop(),
+                           const uint32_t* maskQ = nullptr, const uint32_t* maskK = nullptr) {
     dim3 grid(attn_grid((D.nt + 3) / 4, D.B * D.h));
     const float scale = 1.0f / sqrtf((float)D.L.dk);
+    if (drop.thr16 && (!maskQ || !maskK)) return fail(MMT_EINVAL, "attention dropout without mask buffers");
     static const bool fused = getenv("MMT_NO_FUSED_ATTN_BWD") == nullptr;
     if (fused && attn_bwd_fused_ok(DKP, D.nt)) {        // one evaluation of P and dS per score: attn_bwd_fused.h
         static bool configured = false;
@@ -279,7 +315,7 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
         }
         ProfScope prof(S_ATTN_BWD_FUSED, st);
 #define MMT_FUSED(dr) hipLaunchKernelGGL((attn_bwd_fused16_kernel<dr>), dim3(D.B * D.h), dim3(MMT_FUSED_THREADS), MMT_FUSED_LDS_BYTES, st, \
-                                          QR, QT, KR, KT_, VR, dOR, dOT, lse, delta, rowmask, scale, dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, drop)
+                                          QR, QT, KR, KT_, VR, dOR, dOT, lse, delta, rowmask, scale, dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, maskK, drop.scale)
         if (drop.thr16) MMT_FUSED(true); else MMT_FUSED(false);
 #undef MMT_FUSED
         LAUNCH_CHECK("attn_bwd_fused16_kernel");
@@ -288,7 +324,7 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
     {
         ProfScope prof(S_ATTN_BWD, st);
 #define MMT_DKV(dkp, dr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, QT, KR, VR, dOR, dOT, lse, delta, \
-                                            dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, D.B * D.h, drop)
+                                            dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, D.B * D.h, maskK, drop.scale)
         if (DKP == 16) { if (drop.thr16) MMT_DKV(16, true); else MMT_DKV(16, false); }
         else { if (drop.thr16) MMT_DKV(32, true); else MMT_DKV(32, false); }
 #undef MMT_DKV
@@ -297,7 +333,7 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
     {
         ProfScope prof(S_ATTN_BWD_DQ, st);
 #define MMT_DQ(dkp, dr) hipLaunchKernelGGL((attn_bwd_dq_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, KT_, VR, dOR, lse, delta, rowmask, \
-                                           scale, dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, D.B * D.h, drop)
+                                           scale, dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, D.B * D.h, maskQ, drop.scale)
         if (DKP == 16) { if (drop.thr16) MMT_DQ(16, true); else MMT_DQ(16, false); }
         else { if (drop.thr16) MMT_DQ(32, true); else MMT_DQ(32, false); }
 #undef MMT_DQ
@@ -349,6 +385,9 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
                            params, W.wprep, W.bprep, L);
         LAUNCH_CHECK("encoder_prep_kernel");
     }
+    if (D.N > 0 && dropout_p > 0.f) {      // every attention-dropout decision of this forward pass (and of its backward), all layers
+        if ((rc = launch_mask_gen(W.lw[0].maskQ, W.lw[0].maskK, D, D.N, dropout_p, seed, st))) return rc;
+    }
     const float* xin = x;
     static const bool fuse_next_qkv = getenv("MMT_NO_CHAIN4") == nullptr;
     for (int l = 0; l < D.N; ++l) {
@@ -377,7 +416,7 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
             if ((rc = launch_rowgemm<EPI_FRAG, true>(p, st, S_LN1_QKV))) return rc;
         }
         // dropout streams of layer l: 4l+0 attention probabilities (:33), 4l+1 / 4l+3 sublayer outputs (:104), 4l+2 FFN hidden (:20)
-        if ((rc = launch_attn_fwd(L.DKP, w.QR, w.KR, w.VT, w.ctx, w.ctxT, w.lse, D, st, make_drop(dropout_p, seed, 4 * l + 0)))) return rc;
+        if ((rc = launch_attn_fwd(L.DKP, w.QR, w.KR, w.VT, w.ctx, w.ctxT, w.lse, D, st, make_drop(dropout_p, seed, 4 * l + 0), w.maskQ))) return rc;
         {   // out-proj + residual -> LN2 + FFN1 + ReLU -> FFN2 + residual, one kernel, x1 and hid stay in LDS
             RowChain3 ch; memset(&ch, 0, sizeof(ch));
             {   RowGemmParams& p = ch.a; p = rg_zero();
@@ -508,7 +547,7 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             if ((rc = launch_rowchain(encoder_pre_attn_bwd_kernel, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st))) return rc;
         }
         if ((rc = launch_attn_bwd(L.DKP, w.QR, w.QT, w.KR, w.KT, w.VR, W.dOR, W.dOT, w.lse, W.delta, mask,
-                                  W.dqkv, w.dqkvT, D, st, make_drop(dropout_p, seed, 4 * l + 0)))) return rc;
+                                  W.dqkv, w.dqkvT, D, st, make_drop(dropout_p, seed, 4 * l + 0), w.maskQ, w.maskK))) return rc;
         float* dxin = (l > 0) ? cur : dx;
         {   // dx = dx1 + LN1bwd(dQKV Wqkv)
             RowGemmParams p = rg_zero();
@@ -618,7 +657,7 @@ __global__ void unpad_heads_kernel(const bf16* __restrict__ src, int ld, int col
     }
 }
 
-struct SdpaWs { bf16 *QR, *QT, *KR, *KT, *VR, *VT, *dOR, *dOT, *ctx, *ctxT, *dqkv, *dqkvT; float *lse, *delta; size_t bytes; };
+struct SdpaWs { bf16 *QR, *QT, *KR, *KT, *VR, *VT, *dOR, *dOT, *ctx, *ctxT, *dqkv, *dqkvT; float *lse, *delta; uint32_t *maskQ, *maskK; size_t bytes; };
 static void carve_sdpa(SdpaWs& W, const EncDims& D, void* base) {
     Carver c(base);
     const LayerLayout& L = D.L;
@@ -629,7 +668,14 @@ static void carve_sdpa(SdpaWs& W, const EncDims& D, void* base) {
     W.ctx = c.take<bf16>(M * L.HDP); W.ctxT = c.take<bf16>((size_t)L.HDP * D.MP);
     W.dqkv = c.take<bf16>(M * L.NQ); W.dqkvT = c.take<bf16>((size_t)L.NQ * D.MP);
     W.lse = c.take<float>(BH * D.Tp); W.delta = c.take<float>(BH * D.Tp);
+    W.maskQ = c.take<uint32_t>(attn_mask_layer_words(D.B * D.h, D.nt)); W.maskK = c.take<uint32_t>(attn_mask_layer_words(D.B * D.h, D.nt));
     W.bytes = c.off;
+}
+
+static int check_drop(float dropout_p, const EncDims& D) {
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(MMT_EINVAL, "dropout_p %g not in [0,1)", dropout_p);
+    if (dropout_p > 0.f && D.Tp > 4096) return fail(MMT_EUNSUPPORTED, "train-mode dropout supports T <= 4096 (got %d)", D.T);
+    return MMT_OK;
 }
 
 extern "C" size_t mmt_sdpa_workspace_bytes(int B, int T, int d, int h) {
@@ -640,11 +686,13 @@ extern "C" size_t mmt_sdpa_workspace_bytes(int B, int T, int d, int h) {
 }
 
 extern "C" int mmt_sdpa_forward(const float* q, const float* k, const float* v, const float* mask, float* ctx,
-                                void* workspace, size_t workspace_bytes, int B, int T, int d, int h, mmt_stream_t stream) {
+                                void* workspace, size_t workspace_bytes, int B, int T, int d, int h,
+                                float dropout_p, uint64_t seed, mmt_stream_t stream) {
     EncDims D;
     int rc = make_dims(D, B, T, d, h, 4, 0);
     if (rc) return rc;
     if (!q || !k || !v || !ctx || !workspace) return fail(MMT_EINVAL, "null pointer argument");
+    if ((rc = check_drop(dropout_p, D))) return rc;
     SdpaWs W; carve_sdpa(W, D, workspace);
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -655,18 +703,21 @@ extern "C" int mmt_sdpa_forward(const float* q, const float* k, const float* v, 
     hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, k, W.KR, W.KT, nullptr, 1.f, 0, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
     hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, v, W.VR, W.VT, nullptr, 1.f, 0, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
     LAUNCH_CHECK("pack_frag_kernel");
-    if ((rc = launch_attn_fwd(L.DKP, W.QR, W.KR, W.VT, W.ctx, W.ctxT, W.lse, D, st))) return rc;
+    if (dropout_p > 0.f && (rc = launch_mask_gen(W.maskQ, W.maskK, D, 1, dropout_p, seed, st))) return rc;
+    if ((rc = launch_attn_fwd(L.DKP, W.QR, W.KR, W.VT, W.ctx, W.ctxT, W.lse, D, st, make_drop(dropout_p, seed, 0), W.maskQ))) return rc;
     hipLaunchKernelGGL(unpad_heads_kernel, dim3(grid_for((size_t)D.M * d)), dim3(256), 0, st, W.ctx, L.HDP, 0, ctx, D.M, h, L.dk, L.DKP, d);
     LAUNCH_CHECK("unpad_heads_kernel");
     return MMT_OK;
 }
 
 extern "C" int mmt_sdpa_backward(const float* dctx, const float* mask, float* dq, float* dk, float* dv,
-                                 void* workspace, size_t workspace_bytes, int B, int T, int d, int h, mmt_stream_t stream) {
+                                 void* workspace, size_t workspace_bytes, int B, int T, int d, int h,
+                                 float dropout_p, uint64_t seed, mmt_stream_t stream) {
     EncDims D;
     int rc = make_dims(D, B, T, d, h, 4, 0);
     if (rc) return rc;
     if (!dctx || !dq || !dk || !dv || !workspace) return fail(MMT_EINVAL, "null pointer argument");
+    if ((rc = check_drop(dropout_p, D))) return rc;
     SdpaWs W; carve_sdpa(W, D, workspace);
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -674,7 +725,8 @@ extern "C" int mmt_sdpa_backward(const float* dctx, const float* mask, float* dq
     hipLaunchKernelGGL(pack_frag_kernel, dim3(grid_for((size_t)D.M * h)), dim3(256), 0, st, dctx, W.dOR, W.dOT, nullptr, 1.f, 0,
                        W.ctx, L.HDP, W.delta, D.M, T, D.Tp, h, L.dk, L.DKP, d);
     LAUNCH_CHECK("pack_frag_kernel");
-    if ((rc = launch_attn_bwd(L.DKP, W.QR, W.QT, W.KR, W.KT, W.VR, W.dOR, W.dOT, W.lse, W.delta, mask, W.dqkv, W.dqkvT, D, st))) return rc;
+    if ((rc = launch_attn_bwd(L.DKP, W.QR, W.QT, W.KR, W.KT, W.VR, W.dOR, W.dOT, W.lse, W.delta, mask, W.dqkv, W.dqkvT, D, st,
+                              make_drop(dropout_p, seed, 0), W.maskQ, W.maskK))) return rc;     // the masks the forward generated
     const int g = grid_for((size_t)D.M * d);
     hipLaunchKernelGGL(unpad_heads_kernel, dim3(g), dim3(256), 0, st, W.dqkv, L.NQ, 0, dq, D.M, h, L.dk, L.DKP, d);
     hipLaunchKernelGGL(unpad_heads_kernel, dim3(g), dim3(256), 0, st, W.dqkv, L.NQ, L.HD, dk, D.M, h, L.dk, L.DKP, d);
@@ -1090,15 +1142,9 @@ extern "C" int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* cha
 // kernels used and replay the reference arithmetic with them.
 // attn_Tp == 0: flat stream (index i).  attn_Tp > 0: attention-probability stream, i = (bh*Tp + q)*Tp + key, which the
 // attention kernels evaluate as a per-(batch,head) stream with the 32-bit index q*Tp + key.
-__global__ void dropout_mask_kernel(DropCfg c, uint64_t n, uint32_t attn_Tp, uint8_t* __restrict__ keep) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        if (attn_Tp == 0) { keep[i] = drop_keep(c, i) ? 1 : 0; continue; }
-        const uint64_t per = (uint64_t)attn_Tp * attn_Tp;
-        const uint32_t bh = (uint32_t)(i / per), idx = (uint32_t)(i - (uint64_t)bh * per);
-        const DropCfg dc = drop_substream(c, bh);
-        const uint32_t w = drop_word_idx32(dc, idx);
-        keep[i] = (((idx & 1) ? (w >> 16) : (w & 0xFFFFu)) >= c.thr16) ? 1 : 0;
-    }
+__global__ void dropout_mask_kernel(DropCfg c, uint64_t n, uint8_t* __restrict__ keep) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        keep[i] = drop_keep(c, i) ? 1 : 0;
 }
 // Test hook: leave a chosen bit pattern in every LDS word (and a spread of VGPRs) of every CU.  A kernel whose result depends on LDS
 // it never wrote (what a freshly powered GPU hands it: the first process on a box) then produces a different answer after this call.
@@ -1142,7 +1188,15 @@ extern "C" int mmt_debug_dropout_mask(float p, uint64_t seed, uint32_t stream_id
     if (!keep) return fail(MMT_EINVAL, "null pointer argument");
     const DropCfg c = make_drop(p, seed, stream_id);
     if (scale_out) *scale_out = c.scale;        // host pointer
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), c, n, attn_Tp, keep);
+    if (attn_Tp) {                              // attention-probability stream: the generator's own block function (attn_mask.h)
+        if (attn_Tp % 32 || n % ((uint64_t)attn_Tp * attn_Tp)) return fail(MMT_EINVAL, "attention mask: n must be a multiple of Tp*Tp, Tp of 32");
+        const int nt = (int)(attn_Tp / 32), nbh = (int)(n / ((uint64_t)attn_Tp * attn_Tp));
+        const size_t blocks = (size_t)nbh * nt * nt;
+        hipLaunchKernelGGL(attn_mask_expand_kernel, dim3((unsigned)((blocks + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), c, nbh, nt, keep);
+        LAUNCH_CHECK("attn_mask_expand_kernel");
+        return MMT_OK;
+    }
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), c, n, keep);
     LAUNCH_CHECK("dropout_mask_kernel");
     return MMT_OK;
 }

@@ -13,6 +13,7 @@
 #pragma once
 #include <type_traits>
 #include "common.h"
+#include "attn_mask.h"
 
 // ------------------------------------------------------------------------------------------------
 // All three kernels below: a 1-D grid decoded by attn_block() into (tile quad, batch*head), 4 waves per workgroup, each wave owning one 32-window
@@ -51,31 +52,6 @@ struct TileStager {
     }
 };
 
-// per-(batch,head) dropout stream on the probabilities.  One hash word serves the key pair (2c, 2c+1) of query q; its index is
-// q*(Tp/2) + c  (< 2^24: host code rejects dropout for Tp > 4096).  The hash is split (common.h) into drop_lin, linear in the index,
-// and the avalanche drop_fin, so a kernel pays ONE add per word for the index:
-//   * query on the lane (forward, dQ): xq = drop_lin(q*Tp/2 + 2hh) is a lane constant, a key tile adds kt*16*C1 (scalar), and the
-//     eight words of a tile sit at compile-time steps from there;
-//   * key on the lane (dK/dV): see attn_bwd_dkv_kernel.
-__device__ __forceinline__ uint32_t drop_xq(const DropCfg& dc, int q, int Tp, int hh) {
-    return drop_lin(dc.s0, (uint32_t)q * ((uint32_t)Tp >> 1) + 2u * (uint32_t)hh);
-}
-template <int QUAD_PERM> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, QUAD_PERM, 0xF, 0xF, true);
-}
-__device__ __forceinline__ uint32_t drop_xt(uint32_t xq, int kt) { return xq + (uint32_t)kt * (16u * MMT_DROP_C1); }
-// word of accumulator registers (i, i+1), i even: keys acc32_row(i, hh), +1 of the tile
-__device__ __forceinline__ uint32_t drop_qlane_word(const DropCfg& dc, uint32_t xt, int i) {
-    return drop_fin(xt + (uint32_t)(((i & 3) >> 1) + 4 * (i >> 2)) * MMT_DROP_C1, dc.s1);
-}
-// Half-word keep selects: (half of w) >= thr16 ? v : 0.  The high half compiles to v_cmp_ge_u32_sdwa + v_cndmask; for the low half
-// hipcc emits an AND plus a 32-bit compare, so that one is written out (v_cmp_le_u16 reads the low 16 bits of its operands).
-__device__ __forceinline__ float keep_lo_sel(uint32_t w, uint32_t thr16, float v) {
-    float r;
-    asm("v_cmp_le_u16 vcc, %1, %2\n\tv_cndmask_b32 %0, 0, %3, vcc" : "=v"(r) : "v"(thr16), "v"(w), "v"(v) : "vcc");
-    return r;
-}
-__device__ __forceinline__ float keep_hi_sel(uint32_t w, uint32_t thr16, float v) { return (w >> 16) >= thr16 ? v : 0.f; }
 // all 16 registers = x in eight 64-bit moves (hipcc writes a splat as sixteen v_mov_b32).  The trailing s_nop covers the two
 // wait states an MFMA needs after a VALU write of its SrcC: the hazard recognizer does not see through asm statements.
 __device__ __forceinline__ void fill16(f32x16& v, float x) {
@@ -88,16 +64,6 @@ __device__ __forceinline__ void fill16(f32x16& v, float x) {
         v[i] = t[0]; v[i + 1] = t[1];
     }
 }
-// zeroes the dropped probabilities; the caller owes the factor 1/(1-p) (the forward applies it once, to the output row)
-__device__ __forceinline__ void drop_probs_qlane(f32x16& v, const DropCfg& dc, uint32_t xt) {
-#pragma unroll
-    for (int i = 0; i < 16; i += 2) {       // registers (i, i+1) hold adjacent keys
-        const uint32_t w = drop_qlane_word(dc, xt, i);
-        v[i] = keep_lo_sel(w, dc.thr16, v[i]);
-        v[i + 1] = keep_hi_sel(w, dc.thr16, v[i + 1]);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Forward.  S^T = K Q'^T puts the query on the lane column: running max / sum / rescale are lane-local and
 // the only cross-lane step is one exchange between the two 32-lane halves.  After the first key tile the
@@ -124,16 +90,18 @@ __device__ __forceinline__ AttnBlock attn_block(int nx, int nbh) {
 }
 __host__ inline int attn_grid(int nx, int nbh) { return nx * 8 * ((nbh + 7) / 8); }
 
-template <int DKP, bool DROP>
+// ABL != 0: timing-only ablations (results are WRONG; tools/attn_ablate.py): 1 no running max / rescale, 2 no exp,
+// 3 no PV product, 4 operands straight from global memory (no LDS staging, no barrier), 5 no row sums
+template <int DKP, bool DROP, int ABL = 0>
 __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
         const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vt,
         bf16* __restrict__ ctx, bf16* __restrict__ ctxT, float* __restrict__ lse,
-        int h, int T, int nt, int nbh, int ldc, int MP, DropCfg drop) {
+        int h, int T, int nt, int nbh, int ldc, int MP, const uint32_t* __restrict__ maskQ, float drop_scale) {
     constexpr int KS = DKP / 16;
     constexpr bool ONES = (DKP == 16) && !DROP;        // row sums through the MFMA
     constexpr int PK = DKP * 4, PV = 128;              // 16-byte pieces of one K (R layout) / V (T layout) tile
     __shared__ __attribute__((aligned(16))) bf16 stage[2][(PK + PV) * 8];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const AttnBlock ab = attn_block((nt + 3) >> 2, nbh);
     if (!ab.valid) return;                              // whole workgroup, before any barrier
@@ -145,8 +113,8 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
     const bf16* Qb = Qr + (size_t)bh * fragR_elems(Tp, DKP);
     const bf16* Kb = Kr + (size_t)bh * fragR_elems(Tp, DKP);
     const bf16* Vb = Vt + (size_t)bh * fragT_elems(Tp);
-    const DropCfg dc = DROP ? drop_substream(drop, (uint32_t)bh) : drop;       // per-(batch,head) stream
-    const uint32_t xq = DROP ? drop_xq(dc, qtc * 32 + r, Tp, hh) : 0u;
+    // dropout: this wave's row of 32x32 mask blocks (attn_mask.h, MQ layout), one block per key tile
+    const uint64_t* mrow = reinterpret_cast<const uint64_t*>(maskQ) + ((size_t)bh * nt + qtc) * nt * 16;
 
     TileStager<2, (PK + PV + MMT_THREADS - 1) / MMT_THREADS> stg;
     {
@@ -176,9 +144,11 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
     // last key tile, whose index masking is then straight-line code.
     auto body = [&](auto tail_tag, int kt) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        if (!TAIL) stg.load(kt + 1);                    // next tile in flight behind this tile's arithmetic
-        const bf16* sk = stage[kt & 1];
-        const bf16* sv = sk + PK * 8;
+        TileMask tm;
+        if (DROP) tm = load_tile_mask(mrow, kt);        // two scalar loads, consumed after the exponentials
+        if (!TAIL && ABL != 4) stg.load(kt + 1);        // next tile in flight behind this tile's arithmetic
+        const bf16* sk = (ABL == 4) ? Kb + (size_t)kt * 32 * DKP : stage[kt & 1];
+        const bf16* sv = (ABL == 4) ? Vb + (size_t)kt * 1024 : sk + PK * 8;
         f32x16 s;
         fill16(s, (kt == 0) ? 0.f : -mrun);
 #pragma unroll
@@ -189,12 +159,15 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
             for (int i = 0; i < 16; ++i) s[i] = (kt * 32 + acc32_row(i, hh) < T) ? s[i] : -INFINITY;
         }
         // (no inline asm here: hipcc's hazard recognizer does not count an asm statement as a reader of MFMA results)
-        float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
+        float tmax = 0.f;
+        if (ABL != 1) {
+        tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
         for (int i = 3; i < 15; i += 2) tmax = fmaxf(fmaxf(tmax, s[i]), s[i + 1]);
         tmax = fmaxf(tmax, s[15]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));      // finite: every tile holds >= 1 real key in one of the halves
-        if (kt == 0 || __any(tmax > MMT_RESCALE_THR)) {
+        }
+        if (ABL != 1 && (kt == 0 || __any(tmax > MMT_RESCALE_THR))) {
             // move the reference to the new running max (first tile: from 0 to the tile max, with o = l = 0)
             const float dlt = (kt == 0) ? tmax : fmaxf(tmax, 0.f);
             const float alpha = fast_exp2(-dlt);
@@ -204,22 +177,31 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
             for (int i = 0; i < 16; ++i) { o[i] *= alpha; s[i] -= dlt; }
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = fast_exp2(s[i]);
-        if (!ONES) {                                    // row sum of the tile in packed adds
-            f32x2 p2 = {s[0], s[1]};
-#pragma unroll
-            for (int i = 2; i < 16; i += 2) { const f32x2 t = {s[i], s[i + 1]}; p2 += t; }
-            lrun += p2[0] + p2[1];
+        for (int i = 0; i < 16; ++i) s[i] = (ABL == 2) ? s[i] * 0.01f : fast_exp2(s[i]);
+        if (!ONES && ABL != 5) {        // row sum of the tile as ONE chain of plain adds: a wave issues a vector instruction every 6+ cycles
+            float a = s[0];             // anyway, so the dependency costs nothing, and a v_add_f32 takes 1.6 cycles of SIMD issue where the
+#pragma unroll                          // v_pk_add_f32 that two parallel chains get packed into takes 3.7 (tools/valu_micro.hip)
+            for (int i = 1; i < 16; ++i) a += s[i];
+            lrun += a;
         }
-        if (DROP) drop_probs_qlane(s, dc, drop_xt(xq, kt));
+        if (DROP) {                                     // zero the dropped probabilities; 1/(1-p) is applied once, to the output row
+            keep_sel8(s, 0, tm); keep_sel8(s, 8, tm);
+        }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             bf16x8 va = *reinterpret_cast<const bf16x8*>(sv + ((s2 * 2 + hh) * 32 + r) * 8);
             if (ONES && r == DKP) va = ones;           // V^T rows >= DKP are zero in memory; row DKP becomes the ones row
+            if (ABL == 3) {
+                const bf16x8 pk = pack8(s, s2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[8 * s2 + j] += (float)pk[j] + (float)va[j];
+            } else
             o = mfma32(va, pack8(s, s2), o);
         }
+        if (ABL != 4) {
         if (!TAIL) stg.store(stage[(kt + 1) & 1]);
         __syncthreads();        // stage[(kt+1)&1] was last read at tile kt-1, i.e. before the previous barrier
+        }
     };
     for (int kt = 0; kt < nt - 1; ++kt) body(std::false_type{}, kt);
     body(std::true_type{}, nt - 1);
@@ -227,7 +209,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
     float ltot;
     if (ONES) ltot = __shfl(o[8], r);                  // O^T row 16 = (register 8, lower half): the row sums
     else ltot = lrun + __shfl_xor(lrun, 32);
-    const float inv = (DROP ? dc.scale : 1.0f) / ltot;      // kept probabilities carry 1/(1-p)
+    const float inv = (DROP ? drop_scale : 1.0f) / ltot;    // kept probabilities carry 1/(1-p)
     const int t = qt * 32 + r;
     if (t < T) {
         const size_t m = (size_t)b * T + t;
@@ -259,12 +241,12 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
         const float* __restrict__ lse, const float* __restrict__ delta,
         bf16* __restrict__ dkv, int lddkv,      // row-major [M][lddkv]; dK at column HD, dV at 2*HD
         bf16* __restrict__ dkvT, int MP,        // T layout  [3*HD rows][MP]
-        int h, int T, int nt, int nbh, DropCfg drop) {
+        int h, int T, int nt, int nbh, const uint32_t* __restrict__ maskK, float drop_scale) {
     constexpr int KS = DKP / 16;
     constexpr int PR = DKP * 4, PT = 128, PC = 8;       // pieces: R-layout tile, T-layout tile, 32 fp32 row constants
     constexpr int TOTAL = 2 * PR + 2 * PT + 2 * PC;
     __shared__ __attribute__((aligned(16))) bf16 stage[2][TOTAL * 8];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const AttnBlock ab = attn_block((nt + 3) >> 2, nbh);
     if (!ab.valid) return;                              // whole workgroup, before any barrier
@@ -275,7 +257,7 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
     const int Tp = nt * 32, HD = h * DKP;
     const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
     const bf16 *Krb = Kr + offR, *Vrb = Vr + offR;
-    const DropCfg dc = DROP ? drop_substream(drop, (uint32_t)bh) : drop;       // per-(batch,head) stream
+    const uint64_t* mrow = reinterpret_cast<const uint64_t*>(maskK) + ((size_t)bh * nt + ktc) * nt * 16;   // MK layout: one block per query tile
 
     TileStager<6, (TOTAL + MMT_THREADS - 1) / MMT_THREADS> stg;
     {
@@ -302,12 +284,6 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
     const int rq = ONEACC ? (r ^ 16) : r;
     const bool key_tail = (ktc == nt - 1) && (T & 31);
     const bool key_ok = (ktc * 32 + r) < T;
-    const uint32_t kcol = (uint32_t)(ktc * 32 + r);
-    // dropout (see the tile body): lane constants of the word index and of the half-word test
-    const uint32_t hC = ((uint32_t)Tp >> 1) * MMT_DROP_C1;                         // step of one query row
-    const uint32_t par = kcol & 1u;
-    const uint32_t xk = DROP ? drop_lin(dc.s0, (kcol >> 1)) + (uint32_t)(4 * hh + (int)par) * hC : 0u;
-    const uint32_t hmask = par ? 0xFFFF0000u : 0x0000FFFFu, hthr = par ? (dc.thr16 << 16) : dc.thr16;
     stg.store(stage[0]);
     __syncthreads();
 
@@ -317,6 +293,8 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
     auto body = [&](auto tail_tag, int qt) {
         constexpr bool QTAIL = decltype(tail_tag)::value;
         const bool more = qt + 1 < nt;                  // scalar, loop-invariant except at the very last tile
+        TileMask tm;
+        if (DROP) tm = load_tile_mask(mrow, qt);
         if (more) stg.load(qt + 1);
         const bf16* sq = stage[qt & 1];
         const bf16* sdo = sq + PR * 8;
@@ -351,20 +329,14 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
         }
         if (DROP) {
             // dropped probabilities Pd = P*m/(1-p):  dV^T += dO^T Pd ;  dS = P * ((dO V^T)*m/(1-p) - delta); delta unchanged.
-            // Word of (query q, this lane's key pair) = fin(xk + q-step): the two lanes of a key pair need the same 16 words, so each
-            // hashes the 8 queries of its own parity (register j = 2k + par) and the pair swaps them by DPP.
-            const uint32_t xt = xk + (uint32_t)qt * (32u * hC);
-            uint32_t mine[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) mine[k] = drop_fin(xt + (uint32_t)(((2 * k) & 3) + 8 * (k >> 1)) * hC, dc.s1);
+            // m comes as the lane mask of register j (MK layout: the key on the lane, query acc32_row(j, hh) in the register)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + 8 * g + 4 * hh);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int j = 4 * g + i;
-                    const uint32_t w = (i & 1) ? quad_bcast<0xF5>(mine[j >> 1]) : quad_bcast<0xA0>(mine[j >> 1]);    // from the odd / even lane of the pair
-                    const float ms = ((w & hmask) >= hthr) ? dc.scale : 0.f;
+                    const float ms = keep_sel(drop_scale, tm.m[j]);
                     dp[j] = s[j] * fmaf(dp[j], ms, d4[i]);
                     s[j] *= ms;
                 }
@@ -422,11 +394,11 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
         const bf16* __restrict__ dOr, const float* __restrict__ lse, const float* __restrict__ delta,
         const float* __restrict__ rowmask, float scale,
         bf16* __restrict__ dqkv, int lddqkv, bf16* __restrict__ dqkvT, int MP,
-        int h, int T, int nt, int nbh, DropCfg drop) {
+        int h, int T, int nt, int nbh, const uint32_t* __restrict__ maskQ, float drop_scale) {
     constexpr int KS = DKP / 16;
     constexpr int PR = DKP * 4, PT = 128;
     __shared__ __attribute__((aligned(16))) bf16 stage[2][(2 * PR + PT) * 8];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const AttnBlock ab = attn_block((nt + 3) >> 2, nbh);
     if (!ab.valid) return;                              // whole workgroup, before any barrier
@@ -437,8 +409,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
     const int Tp = nt * 32;
     const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
     const bf16 *Qrb = Qr + offR, *dOrb = dOr + offR;
-    const DropCfg dc = DROP ? drop_substream(drop, (uint32_t)bh) : drop;       // per-(batch,head) stream
-    const uint32_t xq = DROP ? drop_xq(dc, qtc * 32 + r, Tp, hh) : 0u;
+    const uint64_t* mrow = reinterpret_cast<const uint64_t*>(maskQ) + ((size_t)bh * nt + qtc) * nt * 16;   // MQ layout
 
     TileStager<3, (2 * PR + PT + MMT_THREADS - 1) / MMT_THREADS> stg;
     {
@@ -466,6 +437,8 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
     auto body = [&](auto tail_tag, int kt) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         const bool more = kt + 1 < nt;
+        TileMask tm;
+        if (DROP) tm = load_tile_mask(mrow, kt);
         if (more) stg.load(kt + 1);
         const bf16* sk = stage[kt & 1];
         const bf16* sv = sk + PR * 8;
@@ -490,14 +463,8 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
         }
         if (DROP) {
             // dS = P * ((dO V^T) * m/(1-p) - delta)
-            const uint32_t xt = drop_xt(xq, kt);
 #pragma unroll
-            for (int j = 0; j < 16; j += 2) {
-                const uint32_t w = drop_qlane_word(dc, xt, j);
-                const float m0 = keep_lo_sel(w, dc.thr16, dc.scale), m1 = keep_hi_sel(w, dc.thr16, dc.scale);
-                dp[j] = s[j] * fmaf(dp[j], m0, negD);
-                dp[j + 1] = s[j + 1] * fmaf(dp[j + 1], m1, negD);
-            }
+            for (int j = 0; j < 16; ++j) dp[j] = s[j] * fmaf(dp[j], keep_sel(drop_scale, tm.m[j]), negD);
         } else {
 #pragma unroll
             for (int j = 0; j < 16; ++j) dp[j] *= s[j];

@@ -38,21 +38,22 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
         const float* __restrict__ lse, const float* __restrict__ delta, const float* __restrict__ rowmask, float scale,
         bf16* __restrict__ dqkv, int lddkv,     // row-major [M][lddkv]: dQ at column 0, dK at HD, dV at 2*HD
         bf16* __restrict__ dqkvT, int MP,       // T layout  [3*HD rows][MP]
-        int h, int T, int nt, DropCfg drop) {
+        int h, int T, int nt, const uint32_t* __restrict__ maskK, float drop_scale) {
     constexpr int DKP = 16, PR = 64, PT = 128, PC = 8, TOTAL = MMT_FUSED_STAGE_PIECES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* const stage0 = reinterpret_cast<bf16*>(smem);                                 // [3][TOTAL * 8] bf16: ring of query tiles
     char* const ktl0 = smem + 3 * TOTAL * 16;                                           // [NW][1024]: own K^T tile, its 16 real rows
     char* const kvl0 = ktl0 + MMT_FUSED_NW * 1024;                                      // [NW][2][1024]: own K and V tiles (R layout)
     char* const reg0 = kvl0 + MMT_FUSED_NW * 2048;                                      // [NW][2][REGION]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int kt = wave;
     const bool live = kt < nt;                          // idle waves stage, synchronise and take their share of the dQ reduction
     const int bh = blockIdx.x, b = bh / h, head = bh - b * h;
     const int Tp = nt * 32, HD = h * DKP;
     const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
-    const DropCfg dc = DROP ? drop_substream(drop, (uint32_t)bh) : drop;       // per-(batch,head) stream
+    // dropout: this wave's row of mask blocks (attn_mask.h, MK layout: key on the lane), one block per query tile
+    const uint64_t* mrow = reinterpret_cast<const uint64_t*>(maskK) + ((size_t)bh * nt + (live ? kt : 0)) * nt * 16;
 
     // ---- staging ring: thread p < 400 moves piece p of every tile (segments: Q R, dO R, Q T, dO T, L, delta)
     const bf16* ssrc; int sstride; const bool son = tid < TOTAL;
@@ -99,11 +100,6 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
     const bool key_tail = live && (kt == nt - 1) && (T & 31);
     const uint32_t kcol = (uint32_t)(kt * 32 + r);
-    // dropout lane constants (attn_bwd_dkv_kernel)
-    const uint32_t hC = ((uint32_t)Tp >> 1) * MMT_DROP_C1;
-    const uint32_t par = kcol & 1u;
-    const uint32_t xk = DROP ? drop_lin(dc.s0, (kcol >> 1)) + (uint32_t)(4 * hh + (int)par) * hC : 0u;
-    const uint32_t hmask = par ? 0xFFFF0000u : 0x0000FFFFu, hthr = par ? (dc.thr16 << 16) : dc.thr16;
     // dQ reduction: this lane's output of a tile.  Lanes 0..31: T layout, feature e = wave, query q = lane; lanes 32..63: row-major,
     // query 2*wave + (lane>>4 & 1), feature lane & 15.  Partial word of (e, q): register (e&3) + 4*(e>>3), lane q + 32*((e>>2)&1).
     const int oe = hh ? (lane & 15) : wave, oq = hh ? (2 * wave + ((lane >> 4) & 1)) : r;
@@ -162,6 +158,8 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
         float rm = rowmask ? rowmask[orow ? rmoff : m0] : 1.f;
         char* const region = myreg + (qt & 1) * MMT_FUSED_REGION_BYTES;
         if (live) {
+            TileMask tm;
+            if (DROP) tm = load_tile_mask(mrow, qt);
             const bf16* sqt = stage0 + (size_t)cur * TOTAL * 8 + 2 * PR * 8;
             const bf16* sdt = sqt + PT * 8;
             const float* sd = reinterpret_cast<const float*>(sdt + PT * 8) + 32;
@@ -177,18 +175,13 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
                 for (int j = 0; j < 16; ++j) s[j] *= kmul;
             }
             if (DROP) {
-                const uint32_t xt = xk + (uint32_t)qt * (32u * hC);
-                uint32_t mine[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) mine[k] = drop_fin(xt + (uint32_t)(((2 * k) & 3) + 8 * (k >> 1)) * hC, dc.s1);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + 8 * g + 4 * hh);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int j = 4 * g + i;
-                        const uint32_t w = (i & 1) ? quad_bcast<0xF5>(mine[j >> 1]) : quad_bcast<0xA0>(mine[j >> 1]);
-                        const float ms = ((w & hmask) >= hthr) ? dc.scale : 0.f;
+                        const float ms = keep_sel(drop_scale, tm.m[j]);     // 1/(1-p) where (query of register j, this lane's key) was kept
                         dp[j] = s[j] * fmaf(dp[j], ms, d4[i]);
                         s[j] *= ms;
                     }

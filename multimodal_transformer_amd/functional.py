@@ -143,7 +143,7 @@ def layer_norm(x, a_2, b_2, eps=1e-6):
 
 class _SdpaFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, mask, h):
+    def forward(ctx, q, k, v, mask, h, dropout_p, seed):
         lib = _lib.load()
         _lib.require_hip(q, k, v, mask)
         q_, k_, v_, m_ = _f32c(q), _f32c(k), _f32c(v), _f32c(mask)
@@ -154,13 +154,13 @@ class _SdpaFn(torch.autograd.Function):
             raise NotImplementedError("sdpa: only the reference's query-row mask of shape (B,T,1) is supported")
         nbytes = lib.mmt_sdpa_workspace_bytes(B, T, d, h)
         if nbytes == 0:
-            _lib.check(lib.mmt_sdpa_forward(None, None, None, None, None, None, 0, B, T, d, h, None))
+            _lib.check(lib.mmt_sdpa_forward(None, None, None, None, None, None, 0, B, T, d, h, 0.0, 0, None))
         ws = _lib.POOL.get(nbytes, q_.device, tag=("sdpa", B, T, d, h))
         out = torch.empty_like(q_)
         _lib.check(lib.mmt_sdpa_forward(_lib.ptr(q_), _lib.ptr(k_), _lib.ptr(v_), _lib.ptr(m_), _lib.ptr(out), _lib.ptr(ws), nbytes,
-                                        B, T, d, h, _lib.stream_ptr()))
+                                        B, T, d, h, dropout_p, seed, _lib.stream_ptr()))
         if any(ctx.needs_input_grad):
-            ctx.ws, ctx.cfg, ctx.mask = ws, (B, T, d, h, nbytes), m_
+            ctx.ws, ctx.cfg, ctx.mask = ws, (B, T, d, h, nbytes, dropout_p, seed), m_
         else:
             _lib.POOL.put(ws)
         return out
@@ -168,19 +168,20 @@ class _SdpaFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dctx):
         lib = _lib.load()
-        B, T, d, h, nbytes = ctx.cfg
+        B, T, d, h, nbytes, dropout_p, seed = ctx.cfg
         g = _f32c(dctx)
         dq, dk, dv = (torch.empty_like(g) for _ in range(3))
         _lib.check(lib.mmt_sdpa_backward(_lib.ptr(g), _lib.ptr(ctx.mask), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(ctx.ws),
-                                         nbytes, B, T, d, h, _lib.stream_ptr()))
+                                         nbytes, B, T, d, h, dropout_p, seed, _lib.stream_ptr()))
         _lib.POOL.put(ctx.ws)
         ctx.ws = None
-        return dq, dk, dv, None, None
+        return dq, dk, dv, None, None, None, None
 
 
-def sdpa(q, k, v, mask, h):
-    """q,k,v: (B,T,d) with head i in columns [i*d/h,(i+1)*d/h); mask (B,T,1) blanks query rows; -> (B,T,d)."""
-    return _SdpaFn.apply(q, k, v, mask, int(h))
+def sdpa(q, k, v, mask, h, dropout_p=0.0, seed=0):
+    """q,k,v: (B,T,d) with head i in columns [i*d/h,(i+1)*d/h); mask (B,T,1) blanks query rows; -> (B,T,d).
+    dropout_p / seed: train-mode dropout on the probabilities (transformer/MFT/multiTransformer.py:32-33)."""
+    return _SdpaFn.apply(q, k, v, mask, int(h), float(dropout_p), int(seed))
 
 
 class _LinearFn(torch.autograd.Function):

@@ -64,8 +64,7 @@ def attention(query, key, value, mask=None, dropout=None):
     ``mask`` is the reference's (B,1,T,1) (or (B,T,1)) float mask: rows where it is 0 are blanked.
     Returns (context (B,h,T,d_k), None): the probabilities are not materialised.
     """
-    if dropout is not None and getattr(dropout, "p", 0.0) > 0.0 and getattr(dropout, "training", False):
-        raise NotImplementedError("attention(): probability dropout is only available through the fused Encoder path")
+    p = float(dropout.p) if dropout is not None and getattr(dropout, "training", False) else 0.0     # nn.Dropout: identity in eval
     B, h, T, dk = query.shape
 
     def merge(z):
@@ -76,7 +75,8 @@ def attention(query, key, value, mask=None, dropout=None):
         if mask.numel() != B * T:
             raise NotImplementedError("attention(): only the query-row mask (B,1,T,1)/(B,T,1) of the reference is supported")
         m = mask.reshape(B, T, 1)
-    ctx = F_hip.sdpa(merge(query), merge(key), merge(value), m, h)
+    ctx = F_hip.sdpa(merge(query), merge(key), merge(value), m, h, dropout_p=p,
+                     seed=_lib.next_dropout_seed(query.device, 3) if p > 0.0 else 0)
     return ctx.reshape(B, T, h, dk).transpose(1, 2), None
 
 
@@ -93,9 +93,7 @@ class MultiHeadedAttention(nn.Module):
         self.dropout = nn.Dropout(p=dropout)
 
     def forward(self, query, key, value, mask=None):
-        if self.training and self.dropout.p > 0.0:
-            raise NotImplementedError("MultiHeadedAttention alone: train-mode probability dropout is only available "
-                                      "through the fused Encoder path; call .eval() or set dropout=0")
+        p = float(self.dropout.p) if self.training else 0.0
         B = query.size(0)
         q, k, v = (F_hip.linear(x, l.weight, l.bias) for l, x in zip(self.linears, (query, key, value)))
         m = None
@@ -103,7 +101,7 @@ class MultiHeadedAttention(nn.Module):
             if mask.numel() != B * query.size(1):
                 raise NotImplementedError("only the reference's query-row mask of shape (B,T,1) is supported")
             m = mask.reshape(B, -1, 1)
-        ctx = F_hip.sdpa(q, k, v, m, self.h)
+        ctx = F_hip.sdpa(q, k, v, m, self.h, dropout_p=p, seed=_lib.next_dropout_seed(q.device, 3) if p > 0.0 else 0)
         return F_hip.linear(ctx, self.linears[3].weight, self.linears[3].bias)
 
 

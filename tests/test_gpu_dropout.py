@@ -123,3 +123,86 @@ def test_module_train_mode_runs_and_reseeds(dev):
     assert torch.isfinite(y1).all() and float((y1 - y2).abs().max()) > 1e-3      # a fresh mask per call
     enc.eval()
     assert torch.equal(enc(x, mask), enc(x, mask))
+
+
+@pytest.mark.parametrize("B,T,d,h,lengths,p", [(2, 300, 128, 8, [300, 170], 0.1),      # d_k 16, one-kernel backward
+                                                (2, 70, 256, 8, [70, 33], 0.1),          # d_k 32, two-kernel backward
+                                                (3, 33, 40, 4, [33, 20, 1], 0.25),       # d_k 10 (padded to 16), ragged tail tile
+                                                (1, 520, 128, 8, [520], 0.1)])           # 17 key tiles: two-kernel backward at d_k 16
+def test_standalone_attention_train_mode_replay(dev, B, T, d, h, lengths, p):
+    """attention() / MultiHeadedAttention outside the fused stack apply nn.Dropout to p_attn in train mode
+    (transformer/MFT/multiTransformer.py:31-33): the stored bit masks (stream 0) are extracted and replayed through the oracle,
+    forward and all three input gradients."""
+    F = mta().functional
+    dk = d // h
+    q, k, v = (R.gen_normal("sdpa_drop:%s%d" % (n, d), (B, T, d), 41) for n in "qkv")
+    g = R.gen_normal("sdpa_drop:g%d" % d, (B, T, d), 41)
+    mask = R.prefix_mask(lengths, T)
+    seed = 987654321 + T
+    gl = [t.to(dev).requires_grad_() for t in (q, k, v)]
+    out = F.sdpa(gl[0], gl[1], gl[2], mask.to(dev), h, dropout_p=p, seed=seed)
+    (out * g.to(dev)).sum().backward()
+    Tp = -(-T // 32) * 32
+    keep, scale = F.dropout_mask(p, seed, 0, B * h * Tp * Tp, dev, attn_Tp=Tp)
+    drop = (keep.reshape(B, h, Tp, Tp)[:, :, :T, :T].double() * scale).cpu()
+    frac = 1 - float((drop > 0).double().mean())
+    assert abs(frac - p) < 4 * np.sqrt(p * (1 - p) / drop.numel()) + 2e-5
+
+    def split(z):
+        return z.reshape(B, T, h, dk).permute(0, 2, 1, 3)
+    leaves = [t.double().clone().requires_grad_() for t in (q, k, v)]
+    ref, _ = oracle.scaled_dot_attention(split(leaves[0]), split(leaves[1]), split(leaves[2]), mask.double().unsqueeze(1), drop)
+    ref = ref.permute(0, 2, 1, 3).reshape(B, T, d)
+    (ref * g.double()).sum().backward()
+    tag = "sdpa train T%d d%d p%.2f" % (T, d, p)
+    assert _report(tag + " out", out.detach().cpu(), ref.detach()) < OUT_RTOL
+    for name, a, b in zip("qkv", gl, leaves):
+        assert _report(tag + " d" + name, a.grad.cpu(), b.grad) < 4e-2, name
+    # eval (dropout None / p = 0) differs: dropout really happened
+    with torch.no_grad():
+        assert float((F.sdpa(gl[0], gl[1], gl[2], mask.to(dev), h) - out).abs().max()) > 1e-3
+
+
+def test_attention_mask_statistics(dev):
+    """the stored attention masks: drop fraction p (exact to 2^-16), rows/columns and streams independent, pure function of the seed"""
+    F = mta().functional
+    Tp, nbh = 256, 6
+    n = nbh * Tp * Tp
+    for p in (0.1, 0.25, 0.5):
+        k1, s1 = F.dropout_mask(p, 42, 0, n, dev, attn_Tp=Tp)
+        k2, _ = F.dropout_mask(p, 42, 0, n, dev, attn_Tp=Tp)
+        k3, _ = F.dropout_mask(p, 43, 0, n, dev, attn_Tp=Tp)
+        k4, _ = F.dropout_mask(p, 42, 4, n, dev, attn_Tp=Tp)
+        assert torch.equal(k1, k2)
+        frac = 1 - k1.float().mean().item()
+        assert abs(frac - p) < 4 * np.sqrt(p * (1 - p) / n) + 2e-5
+        assert abs(s1 - 1 / (1 - round(p * 65536) / 65536)) < 1e-6
+        for other in (k3, k4):
+            agree = (k1 == other).float().mean().item()
+            assert abs(agree - (p * p + (1 - p) * (1 - p))) < 6e-3
+        m = k1.reshape(nbh, Tp, Tp).float()
+        # neighbours along the query axis (bits of one generator word), along the key axis (adjacent words) and across heads
+        for a, b in ((m[:, :-1, :], m[:, 1:, :]), (m[:, :, :-1], m[:, :, 1:]), (m[:-1], m[1:])):
+            c = np.corrcoef(a.reshape(-1).cpu().numpy(), b.reshape(-1).cpu().numpy())[0, 1]
+            assert abs(c) < 6e-3
+        # every query row and key column drops about p of its entries
+        assert float((1 - m.mean(dim=2)).sub(p).abs().max()) < 6 * np.sqrt(p * (1 - p) / Tp)
+        assert float((1 - m.mean(dim=1)).sub(p).abs().max()) < 6 * np.sqrt(p * (1 - p) / Tp)
+
+
+def test_multi_headed_attention_module_train_mode(dev):
+    """MultiHeadedAttention used on its own in train mode (the reference's default dropout 0.1): runs, draws a fresh mask per call,
+    passes gradients; eval mode is deterministic"""
+    MT = mta().multiTransformer
+    mha = MT.MultiHeadedAttention(8, 128).to(dev).train()
+    x = R.gen_normal("mha_drop:x", (2, 40, 128), 5).to(dev).requires_grad_()
+    mask = R.prefix_mask([40, 13], 40).to(dev)
+    y1, y2 = mha(x, x, x, mask), mha(x, x, x, mask)
+    assert torch.isfinite(y1).all() and float((y1 - y2).detach().abs().max()) > 1e-4
+    y1.sum().backward()
+    assert torch.isfinite(x.grad).all() and all(torch.isfinite(p.grad).all() for p in mha.parameters())
+    ctx, _ = MT.attention(x.detach().reshape(2, 40, 8, 16).transpose(1, 2), x.detach().reshape(2, 40, 8, 16).transpose(1, 2),
+                          x.detach().reshape(2, 40, 8, 16).transpose(1, 2), mask, torch.nn.Dropout(0.1).train())
+    assert ctx.shape == (2, 8, 40, 16) and torch.isfinite(ctx).all()
+    mha.eval()
+    assert torch.equal(mha(x, x, x, mask), mha(x, x, x, mask))

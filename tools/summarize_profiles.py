@@ -54,7 +54,10 @@ for f in glob.glob(os.path.join(out, "pmc_FETCH_SIZE.json")):
     try:
         line = [l for l in open(f) if l.startswith("{")][-1]
         cfg = json.loads(line)["config"]
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
         res["_meta"] = {"workload": cfg["workload"].split("; fwd")[0], "train": cfg["dropout"].startswith("train"),
+                        "csrc_sha": bench.kernel_source_sha(),
                         "command": "rocprofv3 --kernel-trace --pmc <one counter group per run> -- python3 bench.py --steps 3 --warmup 1 "
                                    "--profile-steps 0 --no-graph --no-full-model --no-cpu-baseline",
                         "units": "averages per dispatch; FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_* bytes = 2*1024*FETCH_SIZE + "
