@@ -102,7 +102,7 @@ static constexpr int MAX_LAYERS = 16;
 
 struct EncDims {
     int B, T, d, h, f, N;
-    int M, MP, Tp, nt, G, nsplit, mchunk, M16;
+    int M, MP, Tp, nt, G, GR, nsplit, mchunk, M16;      // G: 32-window tiles (LayerNorm kernels), GR: row-kernel tiles of MMT_ROWS
     LayerLayout L;
 };
 
@@ -115,7 +115,7 @@ static int make_dims(EncDims& D, int B, int T, int d, int h, int f, int N) {
     if (d < 2) return fail(MMT_EINVAL, "d_model < 2 (unbiased std undefined)");
     D.B = B; D.T = T; D.d = d; D.h = h; D.f = f; D.N = N;
     D.M = B * T; D.MP = round_up(D.M, 64); D.M16 = round_up(D.M, 16);
-    D.Tp = round_up(T, 32); D.nt = D.Tp / 32; D.G = (D.M + 31) / 32;
+    D.Tp = round_up(T, 32); D.nt = D.Tp / 32; D.G = (D.M + 31) / 32; D.GR = (D.M + MMT_ROWS - 1) / MMT_ROWS;
     D.L = make_layout(d, f, h);
     // weight-gradient split over windows: ONE launch covers every layer.  The launch deals (layer, split) units of `tpl` tiles
     // round-robin to the 8 XCDs (wgrad_kernel), and an XCD holds 32 CUs x 4 workgroups (36 KB of LDS each) at a time: pick the
@@ -184,7 +184,7 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
         for (int l = 0; l < D.N; ++l) { W.lw[l].maskQ = mq ? mq + lw * l : nullptr; W.lw[l].maskK = mk ? mk + lw * l : nullptr; }
     }
     for (int l = 0; l < D.N; ++l) {        // contiguous [layer][2 norms][G][2][DP] so one launch reduces them all
-        W.lw[l].lnpart1 = c.take<float>((size_t)D.G * 2 * L.DP); W.lw[l].lnpart2 = c.take<float>((size_t)D.G * 2 * L.DP);
+        W.lw[l].lnpart1 = c.take<float>((size_t)D.GR * 2 * L.DP); W.lw[l].lnpart2 = c.take<float>((size_t)D.GR * 2 * L.DP);
     }
     W.dxa = c.take<float>(M * D.d); W.dxb = c.take<float>(M * D.d);
     W.delta = c.take<float>(BH * D.Tp);
@@ -217,9 +217,9 @@ static int launch_rowgemm(const RowGemmParams& p, hipStream_t st, int site = S_O
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = 160 * 1024;
     }
-    const int grid = (p.M + 31) / 32;
+    const int grid = (p.M + MMT_ROWS - 1) / MMT_ROWS;
     ProfScope prof(site, st);
-    hipLaunchKernelGGL((rowgemm_kernel<EPI, LN>), dim3(grid), dim3(MMT_THREADS), lds, st, p);
+    hipLaunchKernelGGL((rowgemm_kernel<EPI, LN>), dim3(grid), dim3(MMT_RTHREADS), lds, st, p);
     LAUNCH_CHECK("rowgemm_kernel");
     return MMT_OK;
 }
@@ -248,7 +248,7 @@ static int launch_rowchain(K kernel, CH& ch, bool with_g, int site, const char* 
         for (int i = 0; i < 4; ++i) if (!configured[i]) { configured[i] = kp; break; }
     }
     ProfScope prof(site, st);
-    hipLaunchKernelGGL(kernel, dim3((ch.a.M + 31) / 32), dim3(MMT_THREADS), lds, st, ch);
+    hipLaunchKernelGGL(kernel, dim3((ch.a.M + MMT_ROWS - 1) / MMT_ROWS), dim3(MMT_RTHREADS), lds, st, ch);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) return fail(MMT_EHIP, "launch of %s failed: %s", name, hipGetErrorString(e_));
     return MMT_OK;
@@ -583,11 +583,11 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
         LAUNCH_CHECK("encoder_finalize_kernel");
         // the 2N sublayer LayerNorms: partials are contiguous [layer][norm][G][2][DP]; outputs (a_2, b_2) pairs are 2d apart
         // inside a layer block, so launch per norm index with the layer stride
-        const size_t pstride = (size_t)2 * D.G * 2 * L.DP;      // floats between layer l and l+1 for the same norm index
+        const size_t pstride = (size_t)2 * D.GR * 2 * L.DP;     // floats between layer l and l+1 for the same norm index
         for (int k = 0; k < 2; ++k) {
             float* oa = dparams + L.oln(2 * k);
             hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 31) / 32, 2, D.N), dim3(1024), 0, st,
-                               k == 0 ? W.lw[0].lnpart1 : W.lw[0].lnpart2, D.G, L.DP, d, oa, oa + d, pstride, L.stride());
+                               k == 0 ? W.lw[0].lnpart1 : W.lw[0].lnpart2, D.GR, L.DP, d, oa, oa + d, pstride, L.stride());
         }
         LAUNCH_CHECK("ln_param_finalize_kernel");
     }

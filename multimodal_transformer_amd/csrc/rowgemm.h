@@ -2,7 +2,7 @@
 //
 // Every window-local step of the encoder (QKV projection, output projection, the two FFN
 // products, their backward input-gradients, embeds, read-out MLPs) is an instance of this kernel.
-// One workgroup (4 waves) owns 32 consecutive windows:
+// One workgroup (4 waves) owns MMT_ROWS (16) consecutive windows — see "Tile height" below:
 //   1. A tile -> LDS as bf16 [32][KP+8] (optionally through the reference's LayerNorm, computed
 //      in fp32 from an fp32 LDS staging copy; optionally emitting the feature-major "T layout"
 //      copy that the weight-gradient kernel contracts over windows);
@@ -36,6 +36,30 @@ __device__ unsigned long long* g_phase_buf = nullptr;      // [workgroup][stage 
 #endif
 
 enum { EPI_PLAIN = 0, EPI_FRAG = 1, EPI_LNBWD = 2 };
+
+// Tile geometry.  These kernels are bound by INSTRUCTION ISSUE, not by MFMA or memory: a wave issues at most one vector
+// instruction every ~6 cycles and a SIMD only reaches its issue rate with four or more waves (tools/valu_micro.hip), while a
+// stage is a few thousand instructions of staging / LayerNorm / epilogue arithmetic around ~100 cycles of MFMA.  Round 1 ran a
+// 32-window tile on 4 waves at 250+ VGPRs: two workgroups per CU = two waves per SIMD, half the issue slots idle.  Measured
+// alternatives at configs[3]: 16-window tiles x 4 waves (twice the workgroups, four per CU) are SLOWER (+9 % step): the per-wave
+// instruction count barely drops, so the total rises; 32-window tiles x 8 waves keep the total and halve it per wave
+// (<= 128 VGPRs, two workgroups per CU = four waves per SIMD).  MMT_ROWS / MMT_RTHREADS select the geometry at build time.
+#ifndef MMT_ROWS
+#define MMT_ROWS 32
+#endif
+#ifndef MMT_RTHREADS
+#define MMT_RTHREADS 512
+#endif
+static_assert(MMT_ROWS == 16 || MMT_ROWS == 32, "row tile must be 16 or 32 windows");
+static_assert(MMT_RTHREADS == 256 || MMT_RTHREADS == 512, "row kernels run 4 or 8 waves");
+static_assert(MMT_RTHREADS / MMT_ROWS == 8 || MMT_RTHREADS / MMT_ROWS == 16, "8 or 16 threads per row");
+#define MMT_RNW (MMT_RTHREADS / 64)                // waves per workgroup
+#define MMT_RTPR (MMT_RTHREADS / MMT_ROWS)         // threads per row in the row-wise passes (LayerNorm, its backward): 16 or 8
+#define MMT_RG8 (MMT_ROWS / 8)                     // 8-row groups per tile (T-layout copies)
+#define MMT_RSTEP (MMT_RTHREADS / 32)              // row step of the (row, 4 columns) epilogue tasks: rows rbase + RSTEP*it
+#define MMT_RIT (MMT_ROWS / MMT_RSTEP)             // such tasks per thread
+#define MMT_WCOLS (128 / MMT_RNW)                  // columns of a 128-column chunk per wave: 32 (two MFMA tiles) or 16 (one)
+#define MMT_WNT (MMT_WCOLS / 16)
 struct RowGemmParams {
     int M, K, KP, N, NP;
     // ---- A operand ----
@@ -73,9 +97,9 @@ __host__ __device__ inline int rowgemm_fw(int EPI, bool lnpro, int KP, int NP) {
     return fw;
 }
 inline size_t rowgemm_lds_bytes(int EPI, bool lnpro, int KP, int NP) {
-    size_t a = (size_t)32 * (KP + 8) * 2;
-    size_t f = (size_t)32 * (rowgemm_fw(EPI, lnpro, KP, NP) + 4) * 4;
-    size_t g = (EPI == EPI_LNBWD) ? (size_t)32 * (NP + 4) * 4 : 0;
+    size_t a = (size_t)MMT_ROWS * (KP + 8) * 2;
+    size_t f = (size_t)MMT_ROWS * (rowgemm_fw(EPI, lnpro, KP, NP) + 4) * 4;
+    size_t g = (EPI == EPI_LNBWD) ? (size_t)MMT_ROWS * (NP + 4) * 4 : 0;
     return a + f + g;
 }
 
@@ -96,22 +120,24 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     float* Fs = sm.Fs;
     float* Gs = sm.Gs;                                         // LNBWD only
     float* Xs = sm.Xs;
-    const int m0 = blockIdx.x * 32;
+    constexpr int ROWS = MMT_ROWS, TPR = MMT_RTPR, MT = MMT_ROWS / 16;
+    const int m0 = blockIdx.x * ROWS;
     const int l15 = lane & 15, lq = lane >> 4;
     PHASE_DECL
 
     // W fragments of the first chunk's first two k-blocks go in flight NOW: their L2 latency overlaps the A-tile staging
+    // (b*1 / n*1 — the wave's second 16-column MFMA tile — exist only with four waves per workgroup, MMT_WNT == 2)
     bf16x8 b00, b01, b10, b11, n00, n01, n10, n11;
     {
-        const int nb = wave * 32;
+        const int nb = wave * MMT_WCOLS;
         const bf16* wrow0 = p.W + (size_t)((nb < NP ? nb : 0) + l15) * KP + 8 * lq;
         const bf16* wrow1 = wrow0 + (size_t)16 * KP;
-        b00 = *reinterpret_cast<const bf16x8*>(wrow0); b01 = *reinterpret_cast<const bf16x8*>(wrow1);
-        b10 = *reinterpret_cast<const bf16x8*>(wrow0 + 32); b11 = *reinterpret_cast<const bf16x8*>(wrow1 + 32);
+        b00 = *reinterpret_cast<const bf16x8*>(wrow0); b10 = *reinterpret_cast<const bf16x8*>(wrow0 + 32);
+        if (MMT_WNT == 2) { b01 = *reinterpret_cast<const bf16x8*>(wrow1); b11 = *reinterpret_cast<const bf16x8*>(wrow1 + 32); }
         n00 = b00; n01 = b01; n10 = b10; n11 = b11;
         if (KP > 64) {
-            n00 = *reinterpret_cast<const bf16x8*>(wrow0 + 64); n01 = *reinterpret_cast<const bf16x8*>(wrow1 + 64);
-            n10 = *reinterpret_cast<const bf16x8*>(wrow0 + 96); n11 = *reinterpret_cast<const bf16x8*>(wrow1 + 96);
+            n00 = *reinterpret_cast<const bf16x8*>(wrow0 + 64); n10 = *reinterpret_cast<const bf16x8*>(wrow0 + 96);
+            if (MMT_WNT == 2) { n01 = *reinterpret_cast<const bf16x8*>(wrow1 + 64); n11 = *reinterpret_cast<const bf16x8*>(wrow1 + 96); }
         }
     }
 
@@ -122,7 +148,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         if (ASRC == ASRC_GLOBAL) {
             const float* A = static_cast<const float*>(p.A);
             const int k4 = KP >> 2;
-            for (int idx = tid; idx < 32 * k4; idx += MMT_THREADS) {
+            for (int idx = tid; idx < ROWS * k4; idx += MMT_RTHREADS) {
                 const int row = idx / k4, c = (idx - row * k4) * 4, m = m0 + row;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (m < M && c < K) v = *reinterpret_cast<const f32x4*>(A + (size_t)m * p.lda + c);
@@ -130,24 +156,26 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             }
             __syncthreads();
         }
-        // 8 threads per row; LayerNorm of the reference: unbiased std, eps added to std
-        const int row = tid >> 3, j = tid & 7, m = m0 + row;
+        // TPR threads per row; LayerNorm of the reference: unbiased std, eps added to std
+        const int row = tid / TPR, j = tid % TPR, m = m0 + row;
         const float* xr = (ASRC == ASRC_X) ? (Xs + row * sm.ldx) : (Fs + row * ldf);
         float s = 0.f;
-        for (int c = j * 4; c < K; c += 32) { f32x4 v = *reinterpret_cast<const f32x4*>(xr + c); s += (v[0] + v[1]) + (v[2] + v[3]); }
+        for (int c = j * 4; c < K; c += 4 * TPR) { f32x4 v = *reinterpret_cast<const f32x4*>(xr + c); s += (v[0] + v[1]) + (v[2] + v[3]); }
         s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+        if (TPR == 16) s += __shfl_xor(s, 8);
         const float mean = s / (float)K;
         float q = 0.f;
-        for (int c = j * 4; c < K; c += 32) {
+        for (int c = j * 4; c < K; c += 4 * TPR) {
             f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { float dlt = v[i] - mean; q += dlt * dlt; }
         }
         q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+        if (TPR == 16) q += __shfl_xor(q, 8);
         const float sigma = sqrtf(q / (float)(K - 1));
         const float rstd = 1.0f / (sigma + p.eps);
         if (j == 0 && m < M && p.stats) { p.stats[2 * (size_t)m] = mean; p.stats[2 * (size_t)m + 1] = rstd; }
-        for (int c = j * 4; c < KP; c += 32) {
+        for (int c = j * 4; c < KP; c += 4 * TPR) {
             bf16x4 o = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
             if (c < K && m < M) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
@@ -161,7 +189,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     } else if (ASRC == ASRC_X) {
         // fp32 tile kept by the previous stage -> bf16 (optionally through the dropout mask of index m*KP + k)
         const int k4 = KP >> 2;
-        for (int idx = tid; idx < 32 * k4; idx += MMT_THREADS) {
+        for (int idx = tid; idx < ROWS * k4; idx += MMT_RTHREADS) {
             const int row = idx / k4, c = (idx - row * k4) * 4, m = m0 + row;
             bf16x4 o = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
             if (m < M && c < K) {
@@ -181,7 +209,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     } else if (p.a_bf16) {
         const bf16* A = static_cast<const bf16*>(p.A);
         const int k8 = KP >> 3;
-        for (int idx = tid; idx < 32 * k8; idx += MMT_THREADS) {
+        for (int idx = tid; idx < ROWS * k8; idx += MMT_RTHREADS) {
             const int row = idx / k8, c = (idx - row * k8) * 8, m = m0 + row;
             bf16x8 v;
 #pragma unroll
@@ -192,7 +220,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     } else {
         const float* A = static_cast<const float*>(p.A);
         const int k4 = KP >> 2;
-        for (int idx = tid; idx < 32 * k4; idx += MMT_THREADS) {
+        for (int idx = tid; idx < ROWS * k4; idx += MMT_RTHREADS) {
             const int row = idx / k4, c = (idx - row * k4) * 4, m = m0 + row;
             bf16x4 o = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
             if (m < M && c < K) {
@@ -216,8 +244,8 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     if (p.At_out) {   // T-layout copy of the bf16 tile: task = (feature k, group of 8 rows)
         // row group fastest: the 4 lanes of one feature write its 32 windows = 64 contiguous bytes (feature fastest made every
         // lane's 16 bytes a separate write transaction)
-        for (int task = tid; task < KP * 4; task += MMT_THREADS) {
-            const int rg = task & 3, k = task >> 2, mb = m0 + rg * 8;
+        for (int task = tid; task < KP * MMT_RG8; task += MMT_RTHREADS) {
+            const int rg = task % MMT_RG8, k = task / MMT_RG8, mb = m0 + rg * 8;
             if (mb >= M) continue;
             bf16x8 v;
 #pragma unroll
@@ -231,47 +259,53 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     PHASE(1);                                                 // T-layout copy of the A tile
     // ------------------------------------------------------------------ 2. chunks of 128 columns
     for (int n0 = 0; n0 < NP; n0 += 128) {
-        const int nb = n0 + wave * 32;
+        const int nb = n0 + wave * MMT_WCOLS;
         if (nb < NP) {
-            f32x4 acc[2][2];
+            f32x4 acc[MT][MMT_WNT];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < MT; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int b = 0; b < MMT_WNT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
             const bf16* wrow0 = p.W + (size_t)(nb + l15) * KP + 8 * lq;
             const bf16* wrow1 = wrow0 + (size_t)16 * KP;
             const bf16* arow0 = As + l15 * lda_s + 8 * lq;
             const bf16* arow1 = arow0 + 16 * lda_s;
             if (n0 > 0) {                    // (chunk 0's first fragments were issued before the A-tile staging)
-                b00 = *reinterpret_cast<const bf16x8*>(wrow0); b01 = *reinterpret_cast<const bf16x8*>(wrow1);
-                b10 = *reinterpret_cast<const bf16x8*>(wrow0 + 32); b11 = *reinterpret_cast<const bf16x8*>(wrow1 + 32);
+                b00 = *reinterpret_cast<const bf16x8*>(wrow0); b10 = *reinterpret_cast<const bf16x8*>(wrow0 + 32);
+                if (MMT_WNT == 2) { b01 = *reinterpret_cast<const bf16x8*>(wrow1); b11 = *reinterpret_cast<const bf16x8*>(wrow1 + 32); }
             }
             for (int kb = 0; kb < KP; kb += 64) {
                 if (kb + 64 < KP && (kb > 0 || n0 > 0)) {   // next k-block's W fragments in flight behind this block's MFMAs
                     n00 = *reinterpret_cast<const bf16x8*>(wrow0 + kb + 64);
-                    n01 = *reinterpret_cast<const bf16x8*>(wrow1 + kb + 64);
                     n10 = *reinterpret_cast<const bf16x8*>(wrow0 + kb + 96);
-                    n11 = *reinterpret_cast<const bf16x8*>(wrow1 + kb + 96);
+                    if (MMT_WNT == 2) {
+                        n01 = *reinterpret_cast<const bf16x8*>(wrow1 + kb + 64);
+                        n11 = *reinterpret_cast<const bf16x8*>(wrow1 + kb + 96);
+                    }
                 }
                 const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(arow0 + kb);
-                const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(arow1 + kb);
                 const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(arow0 + kb + 32);
-                const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(arow1 + kb + 32);
                 acc[0][0] = mfma16(a00, b00, acc[0][0]);
-                acc[0][1] = mfma16(a00, b01, acc[0][1]);
-                acc[1][0] = mfma16(a01, b00, acc[1][0]);
-                acc[1][1] = mfma16(a01, b01, acc[1][1]);
+                if (MMT_WNT == 2) acc[0][MMT_WNT - 1] = mfma16(a00, b01, acc[0][MMT_WNT - 1]);
+                if (MT == 2) {
+                    const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(arow1 + kb);
+                    acc[MT - 1][0] = mfma16(a01, b00, acc[MT - 1][0]);
+                    if (MMT_WNT == 2) acc[MT - 1][MMT_WNT - 1] = mfma16(a01, b01, acc[MT - 1][MMT_WNT - 1]);
+                }
                 acc[0][0] = mfma16(a10, b10, acc[0][0]);
-                acc[0][1] = mfma16(a10, b11, acc[0][1]);
-                acc[1][0] = mfma16(a11, b10, acc[1][0]);
-                acc[1][1] = mfma16(a11, b11, acc[1][1]);
+                if (MMT_WNT == 2) acc[0][MMT_WNT - 1] = mfma16(a10, b11, acc[0][MMT_WNT - 1]);
+                if (MT == 2) {
+                    const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(arow1 + kb + 32);
+                    acc[MT - 1][0] = mfma16(a11, b10, acc[MT - 1][0]);
+                    if (MMT_WNT == 2) acc[MT - 1][MMT_WNT - 1] = mfma16(a11, b11, acc[MT - 1][MMT_WNT - 1]);
+                }
                 b00 = n00; b01 = n01; b10 = n10; b11 = n11;
             }
-            const int cbase = ((EPI == EPI_LNBWD) ? nb : wave * 32) + l15;
+            const int cbase = ((EPI == EPI_LNBWD) ? nb : wave * MMT_WCOLS) + l15;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < MMT_WNT; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         Fs[(mt * 16 + 4 * lq + r) * ldf + cbase + nt * 16] = acc[mt][nt][r];
@@ -287,15 +321,15 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             // (non-restrict) output pointers would otherwise fence the later tasks' loads and serialise 4 L2 round trips.
             const int cg = tid & 31, n = n0 + cg * 4, rbase = tid >> 5;
             const bool col_ok = n < NP;
-            f32x4 v[4], res[4];
-            bf16x4 mk[4];
-            float rs[4];
+            f32x4 v[MMT_RIT], res[MMT_RIT];
+            bf16x4 mk[MMT_RIT];
+            float rs[MMT_RIT];
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
             if (col_ok && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
             const bool res_vec = p.residual && (n + 4 <= p.N) && ((p.ldr & 3) == 0);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = rbase + 8 * it, m = m0 + row;
+            for (int it = 0; it < MMT_RIT; ++it) {
+                const int row = rbase + MMT_RSTEP * it, m = m0 + row;
                 res[it] = f32x4{0.f, 0.f, 0.f, 0.f};
                 rs[it] = 1.f;
                 if (col_ok && m < M) {
@@ -311,8 +345,8 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                 v[it] = *reinterpret_cast<const f32x4*>(Fs + row * ldf + cg * 4);
             }
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = rbase + 8 * it, m = m0 + row;
+            for (int it = 0; it < MMT_RIT; ++it) {
+                const int row = rbase + MMT_RSTEP * it, m = m0 + row;
                 if (!col_ok) continue;
                 f32x4 x = v[it];
                 if (m < M) {
@@ -346,8 +380,8 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                 v[it] = x;
             }
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = rbase + 8 * it, m = m0 + row;
+            for (int it = 0; it < MMT_RIT; ++it) {
+                const int row = rbase + MMT_RSTEP * it, m = m0 + row;
                 if (!col_ok) continue;
                 if (m < M) {
                     if (p.out_f32) {
@@ -376,9 +410,10 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             if (p.out_T) {
                 __syncthreads();
 #pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int task = tid + it * MMT_THREADS;
-                    const int rg = task & 3, c = task >> 2, n = n0 + c, mb = m0 + rg * 8;       // row group fastest: 64-byte runs
+                for (int it = 0; it < (128 * MMT_RG8 + MMT_RTHREADS - 1) / MMT_RTHREADS; ++it) {      // 128 columns x MMT_RG8 row groups
+                    const int task = tid + it * MMT_RTHREADS;
+                    const int rg = task % MMT_RG8, c = task / MMT_RG8, n = n0 + c, mb = m0 + rg * 8;       // row group fastest: 16 B x MMT_RG8 runs
+                    if (c >= 128) continue;
                     if (n >= NP || mb >= M) continue;
                     bf16x8 v;
 #pragma unroll
@@ -400,11 +435,11 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
             if (col_ok && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
             // phase 1: all global loads of the 4 tasks
-            float sc[4];
-            bf16x4 c4[4];
+            float sc[MMT_RIT];
+            bf16x4 c4[MMT_RIT];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int m = m0 + rbase + 8 * it;
+            for (int it = 0; it < MMT_RIT; ++it) {
+                const int m = m0 + rbase + MMT_RSTEP * it;
                 sc[it] = 1.f;
                 if (col_ok && m < M) {
                     if (p.scale_first && wi == 0) sc[it] = (p.rowmask[m] == 0.0f) ? 0.f : p.qscale;   // mask == 0 -> blank query row
@@ -412,8 +447,8 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                 }
             }
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = rbase + 8 * it, m = m0 + row;
+            for (int it = 0; it < MMT_RIT; ++it) {
+                const int row = rbase + MMT_RSTEP * it, m = m0 + row;
                 const bool ok = col_ok && (m < M);
                 float part = 0.f;
                 int bh = 0, t = 0;
@@ -455,11 +490,11 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                 // The tile now holds the final bf16-rounded values.  Both fragment layouts are written with lanes laid along
                 // the direction that is contiguous in memory (8-byte stores with the lanes across columns cost one write
                 // transaction per lane: 2.5 M transactions per QKV launch at C4):
-                //  R layout [tile][e>>3][t&31][e&7]: lanes across the 32 windows -> 16 bytes per lane, 512-byte runs
+                //  R layout [tile][e>>3][t&31][e&7]: lanes across the tile's windows -> 16 bytes per lane, 256/512-byte runs
 #pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const int q = tid + it * MMT_THREADS, rr = q & 31, cc = q >> 5, nn = n0 + 8 * cc, mm = m0 + rr;
-                    if (nn < p.nwhich * HD && mm < M) {
+                for (int it = 0; it < (MMT_ROWS * 16 + MMT_RTHREADS - 1) / MMT_RTHREADS; ++it) {
+                    const int q = tid + it * MMT_RTHREADS, rr = q % MMT_ROWS, cc = q / MMT_ROWS, nn = n0 + 8 * cc, mm = m0 + rr;
+                    if (cc < 16 && nn < p.nwhich * HD && mm < M) {
                         const int wj = nn / HD, rj = nn - wj * HD, hj = rj / p.DKP, ej = rj - hj * p.DKP;
                         const int b = mm / p.T, t = mm - b * p.T;
                         const f32x4 lo = *reinterpret_cast<const f32x4*>(Fs + rr * ldf + 8 * cc);
@@ -476,8 +511,8 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                 if (nn < p.nwhich * HD) {
                     const int wj = nn / HD, rj = nn - wj * HD, hj = rj / p.DKP, ej = rj - hj * p.DKP;
 #pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const int rg = (tid >> 7) + 2 * it, mg = m0 + 4 * rg;
+                    for (int it = 0; it < (MMT_ROWS / 4) / (MMT_RTHREADS / 128); ++it) {
+                        const int rg = (tid >> 7) + (MMT_RTHREADS / 128) * it, mg = m0 + 4 * rg;
                         if (mg >= M) continue;
                         const int b = mg / p.T, t = mg - b * p.T;
                         const bool second = (t >> 3) & 1;                    // this row group is the j = 4..7 half of its piece
@@ -486,7 +521,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                         bf16x4 o;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) o[i] = (bf16)Fs[(4 * rg + i) * ldf + c];
-                        if (!second && rg + 2 < 8 && t + 8 < p.T) {
+                        if (!second && rg + 2 < MMT_ROWS / 4 && t + 8 < p.T) {
                             bf16x8 o8;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) { o8[i] = o[i]; o8[4 + i] = (bf16)Fs[(4 * rg + 8 + i) * ldf + c]; }
@@ -506,14 +541,14 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     if (EPI == EPI_LNBWD) {
         __syncthreads();
         const int d = p.d_real;
-        const int row = tid >> 3, j = tid & 7, m = m0 + row;
+        const int row = tid / TPR, j = tid % TPR, m = m0 + row;
         float* cr = Fs + row * ldf;          // dxn = grad wrt LayerNorm output (fp32)
         float* gr = Gs + row * (NP + 4);
         float mean = 0.f, rstd = 0.f;
         if (m < M) { mean = p.st[2 * (size_t)m]; rstd = p.st[2 * (size_t)m + 1]; }
         {
         float s1 = 0.f, s2 = 0.f;
-        for (int c = j * 4; c < NP; c += 32) {
+        for (int c = j * 4; c < NP; c += 4 * TPR) {
             f32x4 g = {0.f, 0.f, 0.f, 0.f}, xh = {0.f, 0.f, 0.f, 0.f};
             if (m < M && c < d) {
                 f32x4 dy = *reinterpret_cast<const f32x4*>(cr + c);
@@ -537,10 +572,11 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         }
         s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
         s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
+        if (TPR == 16) { s1 += __shfl_xor(s1, 8); s2 += __shfl_xor(s2, 8); }
         if (m < M) {
             const float sigma = 1.0f / rstd - p.eps;
             const float k1 = s1 / (float)d, k2 = s2 / ((float)(d - 1) * sigma);
-            for (int c = j * 4; c < d; c += 32) {
+            for (int c = j * 4; c < d; c += 4 * TPR) {
                 f32x4 dy = *reinterpret_cast<const f32x4*>(cr + c);
                 f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + c);
                 f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_a + c);
@@ -558,10 +594,10 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         }
         __syncthreads();
         if (p.colpart) {
-            for (int c = tid; c < NP; c += MMT_THREADS) {
+            for (int c = tid; c < NP; c += MMT_RTHREADS) {
                 float sb = 0.f, sa = 0.f;
 #pragma unroll 8
-                for (int r = 0; r < 32; ++r) { sb += Fs[r * ldf + c]; sa += Gs[r * (NP + 4) + c]; }
+                for (int r = 0; r < MMT_ROWS; ++r) { sb += Fs[r * ldf + c]; sa += Gs[r * (NP + 4) + c]; }
                 float* dst = p.colpart + (size_t)blockIdx.x * 2 * NP;
                 dst[c] = sb; dst[NP + c] = sa;
             }
@@ -576,22 +612,22 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
 // the lines come up from MALL into this XCD's L2 while the first stage stages its A tile, so the later stages' W-fragment
 // loads are L2 hits instead of first-touch misses.
 __device__ __forceinline__ void warm_weights(const bf16* W, int NP, int KP) {
-    if ((blockIdx.x & 3) != 0) return;
+    if ((blockIdx.x & (MMT_ROWS == 16 ? 7 : 3)) != 0) return;
     const int lines = (NP * KP) >> 6;                           // 64 bf16 per 128-byte line
     unsigned acc = 0;
-    for (int l = threadIdx.x; l < lines; l += MMT_THREADS) acc |= *reinterpret_cast<const unsigned*>(W + (size_t)l * 64);
+    for (int l = threadIdx.x; l < lines; l += MMT_RTHREADS) acc |= *reinterpret_cast<const unsigned*>(W + (size_t)l * 64);
     asm volatile("" :: "v"(acc));
 }
 
 // ---- single stage ------------------------------------------------------------------------------
 template <int EPI, bool LNPRO>
-__global__ __launch_bounds__(MMT_THREADS, 2) void rowgemm_kernel(const RowGemmParams p) {
+__global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void rowgemm_kernel(const RowGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     RowSmem sm;
     sm.As = reinterpret_cast<bf16*>(smem);
-    sm.Fs = reinterpret_cast<float*>(smem + (size_t)32 * (p.KP + 8) * 2);
+    sm.Fs = reinterpret_cast<float*>(smem + (size_t)MMT_ROWS * (p.KP + 8) * 2);
     sm.ldf = rowgemm_fw(EPI, LNPRO, p.KP, p.NP) + 4;
-    sm.Gs = sm.Fs + (size_t)32 * sm.ldf;
+    sm.Gs = sm.Fs + (size_t)MMT_ROWS * sm.ldf;
     sm.Xs = nullptr; sm.A2 = nullptr; sm.ldx = 0; sm.lda2 = 0;
     rowgemm_stage<EPI, LNPRO, ASRC_GLOBAL, 0>(p, sm);
 }
@@ -602,18 +638,18 @@ struct RowChain4 { RowGemmParams a, b, c, d; int lda_max, ldf, ldx, lda2; };
 
 template <typename CH>
 __host__ __device__ inline size_t rowchain_lds_bytes(const CH& ch, bool with_g) {
-    return (size_t)32 * ch.lda_max * 2 + (size_t)32 * ch.ldf * 4 * (with_g ? 2 : 1) + (size_t)32 * ch.ldx * 4 + (size_t)32 * ch.lda2 * 2;
+    return (size_t)MMT_ROWS * ch.lda_max * 2 + (size_t)MMT_ROWS * ch.ldf * 4 * (with_g ? 2 : 1) + (size_t)MMT_ROWS * ch.ldx * 4 + (size_t)MMT_ROWS * ch.lda2 * 2;
 }
 template <typename CH>
 __device__ __forceinline__ RowSmem rowchain_carve(char* smem, const CH& ch, bool with_g) {
     RowSmem sm;
     sm.As = reinterpret_cast<bf16*>(smem);
-    sm.Fs = reinterpret_cast<float*>(smem + (size_t)32 * ch.lda_max * 2);
+    sm.Fs = reinterpret_cast<float*>(smem + (size_t)MMT_ROWS * ch.lda_max * 2);
     sm.ldf = ch.ldf;
-    sm.Gs = sm.Fs + (size_t)32 * ch.ldf;
-    sm.Xs = sm.Fs + (size_t)32 * ch.ldf * (with_g ? 2 : 1);
+    sm.Gs = sm.Fs + (size_t)MMT_ROWS * ch.ldf;
+    sm.Xs = sm.Fs + (size_t)MMT_ROWS * ch.ldf * (with_g ? 2 : 1);
     sm.ldx = ch.ldx;
-    sm.A2 = reinterpret_cast<bf16*>(sm.Xs + (size_t)32 * ch.ldx);
+    sm.A2 = reinterpret_cast<bf16*>(sm.Xs + (size_t)MMT_ROWS * ch.ldx);
     sm.lda2 = ch.lda2;
     return sm;
 }
@@ -621,7 +657,7 @@ __device__ __forceinline__ RowSmem rowchain_carve(char* smem, const CH& ch, bool
 // Forward, after the attention core of a layer:   x1 = x + drop(ctx Wo^T + bo)        (out-proj + residual; x1 kept in LDS)
 //                                                 hid = drop(relu(LN2(x1) W1^T + b1))  (hid kept in LDS as the next A tile)
 //                                                 x2 = x1 + drop(hid W2^T + b2)        (residual read from LDS)
-__global__ __launch_bounds__(MMT_THREADS, 2) void encoder_post_attn_fwd_kernel(const RowChain3 ch) {
+__global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_post_attn_fwd_kernel(const RowChain3 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, false);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
@@ -632,7 +668,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void encoder_post_attn_fwd_kernel(c
 
 // The same chain followed by the NEXT layer's LayerNorm-1 + Q/K/V projection (its input x2 is already in LDS): every
 // layer but the last.  One launch and one round trip of the residual stream less per layer.
-__global__ __launch_bounds__(MMT_THREADS, 2) void encoder_post_attn_fwd4_kernel(const RowChain4 ch) {
+__global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_post_attn_fwd4_kernel(const RowChain4 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, false);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
@@ -647,7 +683,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void encoder_post_attn_fwd4_kernel(
 //     dh  = (drop'(dx2) W2) * relu'(hid) * drop'          (dh kept in LDS as the next A tile; dx2^T, dh^T emitted for dW)
 //     dx1 = dx2 + LN2bwd(dh W1)                            (kept in LDS)
 //     dO  = drop'(dx1) Wo  -> fragment layouts + delta     (dx1^T emitted for dW)
-__global__ __launch_bounds__(MMT_THREADS, 2) void encoder_pre_attn_bwd_kernel(const RowChain3 ch) {
+__global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_pre_attn_bwd_kernel(const RowChain3 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, true);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
