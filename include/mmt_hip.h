@@ -162,6 +162,13 @@ int mmt_convpool_forward(const float* x, const float* weight, const float* bias,
 int mmt_convpool_backward(const float* x, const float* dout, const int32_t* argmax, float* dweight, float* dbias,
                           void* workspace, size_t workspace_bytes, int N, int W, int D, int F, mmt_stream_t stream);
 
+/* ---- Concordance correlation coefficient per sequence, on the device.
+ * Replaces eval_ccc + the per-sequence host loop of evaluate()     transformer/SFT/train.py:42-50, :236-238
+ * pred, target: (B, T) fp32 row-major (the (B,T,1) valence tensors); lengths: B int32 on the device; sequence b uses its first
+ * lengths[b] windows.  ccc: B float64 on the device: 2 cov / (var_t + var_p + (mean_p - mean_t)^2) with population moments
+ * (np.var, np.cov(bias=True)), accumulated in fp64; NaN for a sequence with fewer than 2 windows or zero spread in both. */
+int mmt_ccc_forward(const float* pred, const float* target, const int32_t* lengths, double* ccc, int B, int T, mmt_stream_t stream);
+
 /* ---- Test hook: the keep-mask (1 = kept) of dropout stream `stream_id` for indices [0,n) under (p, seed), and the
  * scale applied to kept values (host pointer, may be NULL).  Streams used by the encoder stack for layer l:
  * 4l+0 attention probabilities, index ((b*h+head)*Tp + q)*Tp + key (Tp = T rounded up to 32; pass attn_Tp = Tp and

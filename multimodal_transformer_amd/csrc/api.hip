@@ -142,7 +142,7 @@ struct LayerWs {
     // backward operands of the weight-gradient GEMMs, kept per layer so ONE batched launch forms every layer's dW
     bf16 *dx2T, *dhT, *dx1T, *dqkvT;
     float *lnpart1, *lnpart2;
-    uint32_t *maskQ, *maskK;                // attention-dropout lane masks of this layer (attn_mask.h)
+    uint16_t *maskQ, *maskK;                // attention-dropout lane words of this layer (attn_mask.h)
 };
 struct EncWs {
     bf16* wprep; float* bprep; float* statsf;
@@ -179,8 +179,8 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
     }
     {   // attention-dropout bit masks: [layer][bh][tile][tile][32 words], both orientations, written by ONE generator launch
         const size_t lw = attn_mask_layer_words(D.B * D.h, D.nt);
-        uint32_t* mq = c.take<uint32_t>(lw * (size_t)(D.N > 0 ? D.N : 1));
-        uint32_t* mk = c.take<uint32_t>(lw * (size_t)(D.N > 0 ? D.N : 1));
+        uint16_t* mq = c.take<uint16_t>(lw * (size_t)(D.N > 0 ? D.N : 1));
+        uint16_t* mk = c.take<uint16_t>(lw * (size_t)(D.N > 0 ? D.N : 1));
         for (int l = 0; l < D.N; ++l) { W.lw[l].maskQ = mq ? mq + lw * l : nullptr; W.lw[l].maskK = mk ? mk + lw * l : nullptr; }
     }
     for (int l = 0; l < D.N; ++l) {        // contiguous [layer][2 norms][G][2][DP] so one launch reduces them all
@@ -260,10 +260,10 @@ static DropCfg no_drop() { return make_drop(0.f, 0, 0); }
 
 // Attention-probability dropout of `nlayers` layers: ONE launch draws every decision (stream 4l+0 of layer l) into the lane-mask
 // arrays mq / mk (layer l at + l * attn_mask_layer_words).  attn_mask.h.
-static int launch_mask_gen(uint32_t* mq, uint32_t* mk, const EncDims& D, int nlayers, float p, uint64_t seed, hipStream_t st) {
+static int launch_mask_gen(uint16_t* mq, uint16_t* mk, const EncDims& D, int nlayers, float p, uint64_t seed, hipStream_t st) {
     if (nlayers > 16) return fail(MMT_EUNSUPPORTED, "mask generator: %d layers > 16", nlayers);
     MaskGenParams P; memset(&P, 0, sizeof(P));
-    P.mq = mq; P.mk = mk; P.nbh = D.B * D.h; P.nt = D.nt; P.nlayers = nlayers;
+    P.lq = mq; P.lk = mk; P.nbh = D.B * D.h; P.nt = D.nt; P.nlayers = nlayers;
     P.layer_words = attn_mask_layer_words(P.nbh, P.nt);
     for (int l = 0; l < nlayers; ++l) { const DropCfg c = make_drop(p, seed, 4 * l + 0); P.thr16 = c.thr16; P.s0[l] = c.s0; P.s1[l] = c.s1; }
     const size_t blocks = (size_t)P.nbh * P.nt * P.nt;
@@ -273,20 +273,52 @@ static int launch_mask_gen(uint32_t* mq, uint32_t* mk, const EncDims& D, int nla
     return MMT_OK;
 }
 
-// `drop`: the layer's attention dropout (thr16 == 0: off); maskQ: its lane masks, written by launch_mask_gen
+// Even spread of a grid that fits the chip in ONE round.  The dispatcher fills a CU with as many workgroups as its registers and
+// LDS admit before moving on: 1024 workgroups of attn_fwd_kernel (5 fit per CU) land as 5 on some CUs and 3 or none on others, and
+// the launch lasts as long as its fullest CU (measured with in-kernel stamps: wave lifetimes 31k..56k cycles, exits spread over
+// 11 us of a 25 us launch).  Requesting unused dynamic LDS so that exactly ceil(grid / CUs) workgroups fit per CU makes the
+// placement even.  Returns the dynamic LDS bytes to request (0: the grid needs several rounds anyway, or cannot be capped).
+static size_t balance_lds(int grid_wgs, size_t static_lds) {
+    static int cus = 0;
+    if (!cus) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = -1; }
+    if (cus <= 0 || getenv("MMT_NO_BALANCE")) return 0;
+    const int per_cu = (grid_wgs + cus - 1) / cus;
+    if (per_cu > 8) return 0;                                   // beyond any residency limit: several rounds
+    const size_t share = ((size_t)160 * 1024 / per_cu) & ~(size_t)255;
+    if (share <= static_lds + 256) return 0;
+    const size_t next = ((size_t)160 * 1024 / (per_cu + 1));    // must exclude per_cu + 1 workgroups
+    size_t dyn = share - static_lds;
+    if (static_lds + dyn <= next) return 0;
+    return dyn;
+}
+template <typename K> static int allow_big_lds(K kernel, int static_lds) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - static_lds) == hipSuccess ? MMT_OK
+           : fail(MMT_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+}
+
+// `drop`: the layer's attention dropout (thr16 == 0: off); maskQ: its lane words, written by launch_mask_gen
 static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* VT, bf16* ctx, bf16* ctxT, float* lse,
-                           const EncDims& D, hipStream_t st, DropCfg drop = no_drop(), const uint32_t* maskQ = nullptr) {
+                           const EncDims& D, hipStream_t st, DropCfg drop = no_drop(), const uint16_t* maskQ = nullptr) {
     dim3 grid(attn_grid((D.nt + 3) / 4, D.B * D.h));
     if (drop.thr16 && !maskQ) return fail(MMT_EINVAL, "attention dropout without a mask buffer");
+    static bool big = false;
+    if (!big) {
+        int rc2;
+        if ((rc2 = allow_big_lds(&attn_fwd_kernel<16, true>, 6144)) || (rc2 = allow_big_lds(&attn_fwd_kernel<16, false>, 6144)) ||
+            (rc2 = allow_big_lds(&attn_fwd_kernel<32, true>, 8192)) || (rc2 = allow_big_lds(&attn_fwd_kernel<32, false>, 8192))) return rc2;
+        big = true;
+    }
+    const size_t bal = balance_lds((int)grid.x, (size_t)2 * (DKP * 4 + 128) * 16);
     ProfScope prof(S_ATTN_FWD, st);
-#define MMT_FWD(dkp, dr) hipLaunchKernelGGL((attn_fwd_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, \
+#define MMT_FWD(dkp, dr) hipLaunchKernelGGL((attn_fwd_kernel<dkp, dr>), grid, dim3(MMT_THREADS), bal, st, QR, KR, VT, ctx, ctxT, lse, \
                                             D.h, D.T, D.nt, D.B * D.h, D.L.HDP, D.MP, maskQ, drop.scale)
 #ifdef MMT_ABLATIONS
     static const int abl = getenv("MMT_ABL") ? atoi(getenv("MMT_ABL")) : 0;
-#define MMT_FWD_A(a) hipLaunchKernelGGL((attn_fwd_kernel<16, true, a>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, ctxT, lse, \
+#define MMT_FWD_A(a) hipLaunchKernelGGL((attn_fwd_kernel<16, true, a>), grid, dim3(MMT_THREADS), (a == 6 ? (allow_big_lds(&attn_fwd_kernel<16, true, 6>, 6144), bal) : 0), st, QR, KR, VT, ctx, ctxT, lse, \
                                         D.h, D.T, D.nt, D.B * D.h, D.L.HDP, D.MP, maskQ, drop.scale)
     if (abl && DKP == 16 && drop.thr16) {
-        switch (abl) { case 1: MMT_FWD_A(1); break; case 2: MMT_FWD_A(2); break; case 3: MMT_FWD_A(3); break; case 4: MMT_FWD_A(4); break; default: MMT_FWD_A(5); }
+        switch (abl) { case 1: MMT_FWD_A(1); break; case 2: MMT_FWD_A(2); break; case 3: MMT_FWD_A(3); break; case 4: MMT_FWD_A(4); break;
+                       case 5: MMT_FWD_A(5); break; default: MMT_FWD_A(6); }
         LAUNCH_CHECK("attn_fwd_kernel"); return MMT_OK;
     }
 #endif
@@ -301,7 +333,7 @@ static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* 
 static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* KR, const bf16* KT_, const bf16* VR,
                            const bf16* dOR, const bf16* dOT, const float* lse, const float* delta, const float* rowmask,
                            bf16* dqkv, bf16* dqkvT, const EncDims& D, hipStream_t st, DropCfg drop = no_drop(),
-                           const uint32_t* maskQ = nullptr, const uint32_t* maskK = nullptr) {
+                           const uint16_t* maskQ = nullptr, const uint16_t* maskK = nullptr) {
     dim3 grid(attn_grid((D.nt + 3) / 4, D.B * D.h));
     const float scale = 1.0f / sqrtf((float)D.L.dk);
     if (drop.thr16 && (!maskQ || !maskK)) return fail(MMT_EINVAL, "attention dropout without mask buffers");
@@ -657,7 +689,7 @@ __global__ void unpad_heads_kernel(const bf16* __restrict__ src, int ld, int col
     }
 }
 
-struct SdpaWs { bf16 *QR, *QT, *KR, *KT, *VR, *VT, *dOR, *dOT, *ctx, *ctxT, *dqkv, *dqkvT; float *lse, *delta; uint32_t *maskQ, *maskK; size_t bytes; };
+struct SdpaWs { bf16 *QR, *QT, *KR, *KT, *VR, *VT, *dOR, *dOT, *ctx, *ctxT, *dqkv, *dqkvT; float *lse, *delta; uint16_t *maskQ, *maskK; size_t bytes; };
 static void carve_sdpa(SdpaWs& W, const EncDims& D, void* base) {
     Carver c(base);
     const LayerLayout& L = D.L;
@@ -668,7 +700,7 @@ static void carve_sdpa(SdpaWs& W, const EncDims& D, void* base) {
     W.ctx = c.take<bf16>(M * L.HDP); W.ctxT = c.take<bf16>((size_t)L.HDP * D.MP);
     W.dqkv = c.take<bf16>(M * L.NQ); W.dqkvT = c.take<bf16>((size_t)L.NQ * D.MP);
     W.lse = c.take<float>(BH * D.Tp); W.delta = c.take<float>(BH * D.Tp);
-    W.maskQ = c.take<uint32_t>(attn_mask_layer_words(D.B * D.h, D.nt)); W.maskK = c.take<uint32_t>(attn_mask_layer_words(D.B * D.h, D.nt));
+    W.maskQ = c.take<uint16_t>(attn_mask_layer_words(D.B * D.h, D.nt)); W.maskK = c.take<uint16_t>(attn_mask_layer_words(D.B * D.h, D.nt));
     W.bytes = c.off;
 }
 
@@ -998,6 +1030,12 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
     return MMT_OK;
 }
 
+#ifdef MMT_ABLATIONS
+extern "C" int mmt_debug_set_attn_stamp_buffer(void* buf) {
+    unsigned long long* b = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &b, sizeof(b)) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef MMT_PHASE_TIMING
 extern "C" int mmt_debug_set_phase_buffer(void* buf) {
     unsigned long long* b = static_cast<unsigned long long*>(buf);
@@ -1136,6 +1174,15 @@ extern "C" int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* cha
     return MMT_OK;
 }
 
+
+// ------------------------------------------------------------------------------------ metric
+extern "C" int mmt_ccc_forward(const float* pred, const float* target, const int32_t* lengths, double* ccc, int B, int T, mmt_stream_t stream) {
+    if (!pred || !target || !lengths || !ccc) return fail(MMT_EINVAL, "null pointer argument");
+    if (B <= 0 || T <= 0) return fail(MMT_EINVAL, "bad shape B=%d T=%d", B, T);
+    hipLaunchKernelGGL(ccc_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), pred, target, lengths, ccc, T);
+    LAUNCH_CHECK("ccc_kernel");
+    return MMT_OK;
+}
 
 // ------------------------------------------------------------------------------------ test hook
 // keep[i] = 1 if index i of dropout stream `stream` is kept under (p, seed): lets a test rebuild the exact masks the

@@ -79,6 +79,20 @@ __device__ __forceinline__ void fill16(f32x16& v, float x) {
 // to the 8 XCDs, each with a private L2, so a plain 2-D grid would put the sharers on different XCDs and fetch the
 // operands once per sharer from the fabric (measured with FETCH_SIZE: 2.5-3x the operand bytes).  A 1-D grid of
 // nx * 8 * ceil(nbh/8) ids is decoded so that ids congruent mod 8 — same XCD — carry the same head.
+// Progress-based wave priority.  The four waves that share a SIMD in these kernels belong to four different workgroups; the SIMD
+// arbitrates vector issue by priority, then AGE, so at equal priority the oldest wave runs almost unimpeded and the youngest
+// starves: measured wave lifetimes in attn_fwd_kernel spread from 31k to 56k cycles for identical work, and while the last
+// waves finish alone the SIMD issues at a fraction of its four-wave rate (a wave by itself issues one vector instruction per
+// 6-12 cycles: tools/valu_micro.hip).  Each wave therefore LOWERS its priority as it advances through its sweep (3 in the first
+// quarter .. 0 in the last): whoever is behind goes first, the waves of a SIMD finish together, and no tail is left.
+__device__ __forceinline__ void progress_prio(int step, int nsteps) {
+    const int q1 = (nsteps + 3) >> 2, q2 = (nsteps + 1) >> 1, q3 = (3 * nsteps + 3) >> 2;      // wave-uniform
+    if (step == 0) __builtin_amdgcn_s_setprio(3);
+    else if (step == q1) __builtin_amdgcn_s_setprio(2);
+    else if (step == q2) __builtin_amdgcn_s_setprio(1);
+    else if (step == q3) __builtin_amdgcn_s_setprio(0);
+}
+
 struct AttnBlock { int bx, bh; bool valid; };
 __device__ __forceinline__ AttnBlock attn_block(int nx, int nbh) {
     const int L = blockIdx.x, grp = L / (8 * nx), rem = L - grp * 8 * nx;
@@ -91,14 +105,27 @@ __device__ __forceinline__ AttnBlock attn_block(int nx, int nbh) {
 __host__ inline int attn_grid(int nx, int nbh) { return nx * 8 * ((nbh + 7) / 8); }
 
 // ABL != 0: timing-only ablations (results are WRONG; tools/attn_ablate.py): 1 no running max / rescale, 2 no exp,
-// 3 no PV product, 4 operands straight from global memory (no LDS staging, no barrier), 5 no row sums
+// 3 no PV product, 4 operands straight from global memory (no LDS staging, no barrier), 5 no row sums,
+// 6 correct results + s_memtime stamps at seven points of the tile body, summed per wave into g_attn_stamps (diagnostic build)
+#ifdef MMT_ABLATIONS
+__device__ unsigned long long* g_attn_stamps = nullptr;        // [wave id][16]: 0..5, 7 segment sums; 6 wave lifetime; 8 / 9 entry / exit (100 MHz)
+#define ATT_STAMP(n) do { if (ABL == 6) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    st_acc[n] += t_ - st_prev; st_prev = t_; } } while (0)
+#else
+#define ATT_STAMP(n)
+#endif
 template <int DKP, bool DROP, int ABL = 0>
 __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
         const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vt,
         bf16* __restrict__ ctx, bf16* __restrict__ ctxT, float* __restrict__ lse,
-        int h, int T, int nt, int nbh, int ldc, int MP, const uint32_t* __restrict__ maskQ, float drop_scale) {
+        int h, int T, int nt, int nbh, int ldc, int MP, const uint16_t* __restrict__ maskQ, float drop_scale) {
     constexpr int KS = DKP / 16;
     constexpr bool ONES = (DKP == 16) && !DROP;        // row sums through the MFMA
+#ifdef MMT_ABLATIONS
+    unsigned long long st_entry = 0, st_entry_rt = 0;
+    if (ABL == 6) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_entry), "=s"(st_entry_rt) :: "memory");
+#endif
     constexpr int PK = DKP * 4, PV = 128;              // 16-byte pieces of one K (R layout) / V (T layout) tile
     __shared__ __attribute__((aligned(16))) bf16 stage[2][(PK + PV) * 8];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -113,8 +140,9 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
     const bf16* Qb = Qr + (size_t)bh * fragR_elems(Tp, DKP);
     const bf16* Kb = Kr + (size_t)bh * fragR_elems(Tp, DKP);
     const bf16* Vb = Vt + (size_t)bh * fragT_elems(Tp);
-    // dropout: this wave's row of 32x32 mask blocks (attn_mask.h, MQ layout), one block per key tile
-    const uint64_t* mrow = reinterpret_cast<const uint64_t*>(maskQ) + ((size_t)bh * nt + qtc) * nt * 16;
+    // dropout: this lane's 16-bit words of the wave's row of mask blocks (attn_mask.h, LQ layout), one per key tile, fetched a tile ahead
+    const uint16_t* mrow = maskQ + ((size_t)bh * nt + qtc) * nt * 64 + lane;
+    uint32_t mw = DROP ? mrow[0] : 0u;
 
     TileStager<2, (PK + PV + MMT_THREADS - 1) / MMT_THREADS> stg;
     {
@@ -142,10 +170,17 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
     // consumers of its result: hipcc's hazard recognizer counts a skippable block's instructions as MFMA->VALU wait
     // states, which is wrong on the taken path — seen as 27 % wrong dQ in attn_bwd_dq_kernel<32>), TAIL = true for the
     // last key tile, whose index masking is then straight-line code.
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+    (void)st_acc; (void)st_prev;
+#ifdef MMT_ABLATIONS
+    if (ABL == 6) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory");
+#endif
     auto body = [&](auto tail_tag, int kt) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        TileMask tm;
-        if (DROP) tm = load_tile_mask(mrow, kt);        // two scalar loads, consumed after the exponentials
+        ATT_STAMP(7);                                   // loop overhead since the last barrier
+        progress_prio(kt, nt);
+        const uint32_t tw = mw;                          // this tile's keep bits
+        if (DROP && !TAIL) mw = mrow[(size_t)(kt + 1) * 64];
         if (!TAIL && ABL != 4) stg.load(kt + 1);        // next tile in flight behind this tile's arithmetic
         const bf16* sk = (ABL == 4) ? Kb + (size_t)kt * 32 * DKP : stage[kt & 1];
         const bf16* sv = (ABL == 4) ? Vb + (size_t)kt * 1024 : sk + PK * 8;
@@ -167,6 +202,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
         tmax = fmaxf(tmax, s[15]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));      // finite: every tile holds >= 1 real key in one of the halves
         }
+        ATT_STAMP(0);                                   // K fragment read, QK^T, tile maximum, lane exchange
         if (ABL != 1 && (kt == 0 || __any(tmax > MMT_RESCALE_THR))) {
             // move the reference to the new running max (first tile: from 0 to the tile max, with o = l = 0)
             const float dlt = (kt == 0) ? tmax : fmaxf(tmax, 0.f);
@@ -184,9 +220,12 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
             for (int i = 1; i < 16; ++i) a += s[i];
             lrun += a;
         }
+        ATT_STAMP(1);                                   // rescale decision, exponentials, row sums
         if (DROP) {                                     // zero the dropped probabilities; 1/(1-p) is applied once, to the output row
-            keep_sel8(s, 0, tm); keep_sel8(s, 8, tm);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = keep_and(s[i], tw, i);
         }
+        ATT_STAMP(2);                                   // mask wait + selects
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             bf16x8 va = *reinterpret_cast<const bf16x8*>(sv + ((s2 * 2 + hh) * 32 + r) * 8);
@@ -198,13 +237,18 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
             } else
             o = mfma32(va, pack8(s, s2), o);
         }
+        ATT_STAMP(3);                                   // V fragment reads, packs, PV issue
         if (ABL != 4) {
         if (!TAIL) stg.store(stage[(kt + 1) & 1]);
+        ATT_STAMP(4);                                   // wait for the staged tile's global loads + LDS writes
         __syncthreads();        // stage[(kt+1)&1] was last read at tile kt-1, i.e. before the previous barrier
+        ATT_STAMP(5);                                   // barrier
         }
     };
     for (int kt = 0; kt < nt - 1; ++kt) body(std::false_type{}, kt);
     body(std::true_type{}, nt - 1);
+#ifdef MMT_ABLATIONS
+#endif
     if (!live) return;
     float ltot;
     if (ONES) ltot = __shfl(o[8], r);                  // O^T row 16 = (register 8, lower half): the row sums
@@ -226,6 +270,19 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
             for (int i = 0; i < 4; ++i) ctxT[(size_t)(head * DKP + e0 + i) * MP + m] = v[i];
         }
     }
+#ifdef MMT_ABLATIONS
+    if (ABL == 6 && g_attn_stamps) {
+        unsigned long long t1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
+        if (lane == 0) {
+            unsigned long long* q = g_attn_stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
+            for (int i = 0; i < 8; ++i) q[i] = st_acc[i];
+            q[6] = t1 - st_entry; q[8] = st_entry_rt; q[9] = r1;
+            q[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+            q[11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -241,7 +298,7 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
         const float* __restrict__ lse, const float* __restrict__ delta,
         bf16* __restrict__ dkv, int lddkv,      // row-major [M][lddkv]; dK at column HD, dV at 2*HD
         bf16* __restrict__ dkvT, int MP,        // T layout  [3*HD rows][MP]
-        int h, int T, int nt, int nbh, const uint32_t* __restrict__ maskK, float drop_scale) {
+        int h, int T, int nt, int nbh, const uint16_t* __restrict__ maskK, float drop_scale) {
     constexpr int KS = DKP / 16;
     constexpr int PR = DKP * 4, PT = 128, PC = 8;       // pieces: R-layout tile, T-layout tile, 32 fp32 row constants
     constexpr int TOTAL = 2 * PR + 2 * PT + 2 * PC;
@@ -257,7 +314,9 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
     const int Tp = nt * 32, HD = h * DKP;
     const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
     const bf16 *Krb = Kr + offR, *Vrb = Vr + offR;
-    const uint64_t* mrow = reinterpret_cast<const uint64_t*>(maskK) + ((size_t)bh * nt + ktc) * nt * 16;   // MK layout: one block per query tile
+    const uint16_t* mrow = maskK + ((size_t)bh * nt + ktc) * nt * 64 + lane;      // LK layout: this lane's word of one block per query tile
+    uint32_t mw = DROP ? mrow[0] : 0u;
+    const uint32_t scale_bits = __builtin_bit_cast(uint32_t, drop_scale);
 
     TileStager<6, (TOTAL + MMT_THREADS - 1) / MMT_THREADS> stg;
     {
@@ -293,8 +352,9 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
     auto body = [&](auto tail_tag, int qt) {
         constexpr bool QTAIL = decltype(tail_tag)::value;
         const bool more = qt + 1 < nt;                  // scalar, loop-invariant except at the very last tile
-        TileMask tm;
-        if (DROP) tm = load_tile_mask(mrow, qt);
+        progress_prio(qt, nt);
+        const uint32_t tw = mw;
+        if (DROP && more) mw = mrow[(size_t)(qt + 1) * 64];
         if (more) stg.load(qt + 1);
         const bf16* sq = stage[qt & 1];
         const bf16* sdo = sq + PR * 8;
@@ -329,14 +389,14 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
         }
         if (DROP) {
             // dropped probabilities Pd = P*m/(1-p):  dV^T += dO^T Pd ;  dS = P * ((dO V^T)*m/(1-p) - delta); delta unchanged.
-            // m comes as the lane mask of register j (MK layout: the key on the lane, query acc32_row(j, hh) in the register)
+            // m = bit j of the lane's tile word (LK layout: the key on the lane, query acc32_row(j, hh) in register j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + 8 * g + 4 * hh);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int j = 4 * g + i;
-                    const float ms = keep_sel(drop_scale, tm.m[j]);
+                    const float ms = __builtin_bit_cast(float, scale_bits & keep_bits(tw, j));
                     dp[j] = s[j] * fmaf(dp[j], ms, d4[i]);
                     s[j] *= ms;
                 }
@@ -394,7 +454,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
         const bf16* __restrict__ dOr, const float* __restrict__ lse, const float* __restrict__ delta,
         const float* __restrict__ rowmask, float scale,
         bf16* __restrict__ dqkv, int lddqkv, bf16* __restrict__ dqkvT, int MP,
-        int h, int T, int nt, int nbh, const uint32_t* __restrict__ maskQ, float drop_scale) {
+        int h, int T, int nt, int nbh, const uint16_t* __restrict__ maskQ, float drop_scale) {
     constexpr int KS = DKP / 16;
     constexpr int PR = DKP * 4, PT = 128;
     __shared__ __attribute__((aligned(16))) bf16 stage[2][(2 * PR + PT) * 8];
@@ -409,7 +469,9 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
     const int Tp = nt * 32;
     const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
     const bf16 *Qrb = Qr + offR, *dOrb = dOr + offR;
-    const uint64_t* mrow = reinterpret_cast<const uint64_t*>(maskQ) + ((size_t)bh * nt + qtc) * nt * 16;   // MQ layout
+    const uint16_t* mrow = maskQ + ((size_t)bh * nt + qtc) * nt * 64 + lane;      // LQ layout
+    uint32_t mw = DROP ? mrow[0] : 0u;
+    const uint32_t scale_bits = __builtin_bit_cast(uint32_t, drop_scale);
 
     TileStager<3, (2 * PR + PT + MMT_THREADS - 1) / MMT_THREADS> stg;
     {
@@ -437,8 +499,9 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
     auto body = [&](auto tail_tag, int kt) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         const bool more = kt + 1 < nt;
-        TileMask tm;
-        if (DROP) tm = load_tile_mask(mrow, kt);
+        progress_prio(kt, nt);
+        const uint32_t tw = mw;
+        if (DROP && more) mw = mrow[(size_t)(kt + 1) * 64];
         if (more) stg.load(kt + 1);
         const bf16* sk = stage[kt & 1];
         const bf16* sv = sk + PR * 8;
@@ -464,7 +527,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
         if (DROP) {
             // dS = P * ((dO V^T) * m/(1-p) - delta)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) dp[j] = s[j] * fmaf(dp[j], keep_sel(drop_scale, tm.m[j]), negD);
+            for (int j = 0; j < 16; ++j) dp[j] = s[j] * fmaf(dp[j], __builtin_bit_cast(float, scale_bits & keep_bits(tw, j)), negD);
         } else {
 #pragma unroll
             for (int j = 0; j < 16; ++j) dp[j] *= s[j];

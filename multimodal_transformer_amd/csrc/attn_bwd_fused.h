@@ -38,7 +38,7 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
         const float* __restrict__ lse, const float* __restrict__ delta, const float* __restrict__ rowmask, float scale,
         bf16* __restrict__ dqkv, int lddkv,     // row-major [M][lddkv]: dQ at column 0, dK at HD, dV at 2*HD
         bf16* __restrict__ dqkvT, int MP,       // T layout  [3*HD rows][MP]
-        int h, int T, int nt, const uint32_t* __restrict__ maskK, float drop_scale) {
+        int h, int T, int nt, const uint16_t* __restrict__ maskK, float drop_scale) {
     constexpr int DKP = 16, PR = 64, PT = 128, PC = 8, TOTAL = MMT_FUSED_STAGE_PIECES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* const stage0 = reinterpret_cast<bf16*>(smem);                                 // [3][TOTAL * 8] bf16: ring of query tiles
@@ -52,8 +52,10 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
     const int bh = blockIdx.x, b = bh / h, head = bh - b * h;
     const int Tp = nt * 32, HD = h * DKP;
     const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
-    // dropout: this wave's row of mask blocks (attn_mask.h, MK layout: key on the lane), one block per query tile
-    const uint64_t* mrow = reinterpret_cast<const uint64_t*>(maskK) + ((size_t)bh * nt + (live ? kt : 0)) * nt * 16;
+    // dropout: this lane's words of the wave's row of mask blocks (attn_mask.h, LK layout: key on the lane), one per query tile, a tile ahead
+    const uint16_t* mrow = maskK + ((size_t)bh * nt + (live ? kt : 0)) * nt * 64 + lane;
+    uint32_t mw = DROP ? mrow[0] : 0u;
+    const uint32_t scale_bits = __builtin_bit_cast(uint32_t, drop_scale);
 
     // ---- staging ring: thread p < 400 moves piece p of every tile (segments: Q R, dO R, Q T, dO T, L, delta)
     const bf16* ssrc; int sstride; const bool son = tid < TOTAL;
@@ -158,8 +160,8 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
         float rm = rowmask ? rowmask[orow ? rmoff : m0] : 1.f;
         char* const region = myreg + (qt & 1) * MMT_FUSED_REGION_BYTES;
         if (live) {
-            TileMask tm;
-            if (DROP) tm = load_tile_mask(mrow, qt);
+            const uint32_t tw = mw;
+            if (DROP && NEXT) mw = mrow[(size_t)(qt + 1) * 64];
             const bf16* sqt = stage0 + (size_t)cur * TOTAL * 8 + 2 * PR * 8;
             const bf16* sdt = sqt + PT * 8;
             const float* sd = reinterpret_cast<const float*>(sdt + PT * 8) + 32;
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int j = 4 * g + i;
-                        const float ms = keep_sel(drop_scale, tm.m[j]);     // 1/(1-p) where (query of register j, this lane's key) was kept
+                        const float ms = __builtin_bit_cast(float, scale_bits & keep_bits(tw, j));     // 1/(1-p) where (query of register j, this lane's key) was kept
                         dp[j] = s[j] * fmaf(dp[j], ms, d4[i]);
                         s[j] *= ms;
                     }

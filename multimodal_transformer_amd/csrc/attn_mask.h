@@ -3,9 +3,12 @@
 // Round 1 evaluated a counter hash per score inside every attention kernel, forward and backward: 13 cycles of SIMD issue per
 // hash word plus 6 per decision for the compare-and-select, 40 % of the forward's and a third of the backward's instruction
 // stream (tools/valu_micro.hip prices the instructions).  Now one generator launch per forward pass draws every decision of
-// every layer once, 32 decisions per instruction, and stores them as lane masks; a consumer kernel loads the 16 masks of a
-// 32x32 score tile with two scalar loads (s_load_dwordx16) and applies each with ONE v_cndmask_b32 whose select operand is
-// the SGPR pair — no VGPR, no compare, no hash.
+// every layer once, 32 decisions per instruction, and stores them in the order the consumers hold their scores: a consumer lane
+// loads ONE 16-bit word per 32x32 score tile (a tile ahead, with the tile's operand prefetch) and turns bit i into an all-ones /
+// zero word with v_bfe_i32, which it ANDs onto accumulator register i: two full-rate instructions per register, no compare, no
+// hash, no scalar registers.  (A first version kept the masks as 64-bit lane masks in SGPRs, loaded with s_load_dwordx16 and
+// applied with one v_cndmask_b32 per register: fewer vector instructions, but scalar loads share the LDS wait counter, so every
+// tile's first LDS wait exposed the whole scalar-load latency: +5 us per forward launch over eval mode instead of +1.)
 //
 // Bernoulli words.  A 32-bit word whose bits are independent drops with probability thr16 / 65536 is built from up to 16
 // uniform random words, least significant threshold bit first:  D = bit_b ? (D | R_b) : (D & R_b)   (each step halves the
@@ -14,12 +17,12 @@
 // index ((q tile * nt + k tile) * 32 + key) * 16 + b inside the per-(batch, head) substream, so a mask is still a pure
 // function of (seed, layer stream, batch*head, query, key) and mmt_debug_dropout_mask replays it.
 //
-// Layouts (uint32 words; nt = Tp / 32 tiles per axis).  One generator lane owns one 32x32 block and writes it twice:
-//   MQ [bh][q tile][k tile][32]: word 2i + hh = keep bits of key (i&3) + 8(i>>2) + 4hh over the tile's 32 queries (bit = query):
-//      the 64-bit lane mask of accumulator register i for kernels that keep the QUERY on the lane (forward, dQ);
-//   MK [bh][k tile][q tile][32]: the transposed block in the same register order (bit = key): lane masks for kernels that
-//      keep the KEY on the lane (dK/dV, the one-kernel backward).  The 32x32 bit transpose runs in registers (5 butterfly
-//      stages), 64 blocks per wave at once.
+// Layouts (uint16 words; nt = Tp / 32 tiles per axis).  One generator lane owns one 32x32 block and writes it twice, 128 bytes each:
+//   LQ [bh][q tile][k tile][64 lanes]: for kernels that keep the QUERY on the lane (forward, dQ): lane l = 32 hh + q holds, in bit i,
+//      the decision for (query q, key (i&3) + 8(i>>2) + 4hh) — accumulator register i of that lane;
+//   LK [bh][k tile][q tile][64 lanes]: for kernels that keep the KEY on the lane (dK/dV, the one-kernel backward): lane 32 hh + key,
+//      bit j = (query (j&3) + 8(j>>2) + 4hh, key).
+// LQ needs the block transposed (bits over keys): a 32x32 bit transpose in registers (5 butterfly stages), 64 blocks per wave.
 #pragma once
 #include "common.h"
 
@@ -65,31 +68,37 @@ __device__ __forceinline__ void transpose32(uint32_t (&A)[32]) {
     }
 }
 
-// position of row `x` (a key for MQ, a query for MK) inside a stored block: the order of a 32x32 MFMA accumulator's registers
-__device__ __forceinline__ int mask_word_pos(int x) { return 2 * ((x & 3) + 4 * (x >> 3)) + ((x >> 2) & 1); }
+// the 16 bits a consumer lane of half hh needs out of a 32-bit row: bit i of the result = bit (i&3) + 8(i>>2) + 4hh of x
+// (the even / odd nibbles of x, packed)
+__device__ __forceinline__ uint32_t lane_word(uint32_t x, int hh) {
+    uint32_t y = (x >> (4 * hh)) & 0x0F0F0F0Fu;
+    y = (y | (y >> 4)) & 0x00FF00FFu;
+    return (y | (y >> 8)) & 0x0000FFFFu;
+}
 
 struct MaskGenParams {
-    uint32_t* mq; uint32_t* mk;            // layer l at + l * layer_words
+    uint16_t* lq; uint16_t* lk;            // layer l at + l * layer_words
     size_t layer_words;
     int nbh, nt, nlayers;
     uint32_t thr16;
     uint32_t s0[16], s1[16];               // stream keys of the layers' attention dropout (make_drop(p, seed, 4l+0))
 };
 
-__device__ __forceinline__ void store_block(uint32_t* dst, const uint32_t (&W)[32]) {
+// rows[x] = 32 bits over the lane index (x = the register-side index): writes the 64 lane words of one block, 8 x 16 bytes
+__device__ __forceinline__ void store_lane_block(uint16_t* dst, const uint32_t (&rows)[32]) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {          // 16-byte pieces: words 4c .. 4c+3 = registers i = 2c, 2c+1, both halves
+    for (int c = 0; c < 8; ++c) {          // piece c: lanes 8c .. 8c+7, i.e. half hh = c >> 2, lane-side index 8(c&3) .. +7
         u32x4_t v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int p = 4 * c + e, i = p >> 1, hh = p & 1;
-            v[e] = W[(i & 3) + 8 * (i >> 2) + 4 * hh];
+            const int l0 = 8 * (c & 3) + 2 * e, hh = c >> 2;
+            v[e] = lane_word(rows[l0], hh) | (lane_word(rows[l0 + 1], hh) << 16);
         }
-        *reinterpret_cast<u32x4_t*>(dst + 4 * c) = v;
+        *reinterpret_cast<u32x4_t*>(dst + 8 * c) = v;
     }
 }
 
-// one lane per 32x32 block; lanes of a wave walk the k tiles of one (bh, q tile) first: MQ blocks of a wave are contiguous
+// one lane per 32x32 block; lanes of a wave walk the k tiles of one (bh, q tile) first: the LQ blocks of a wave are contiguous
 __global__ __launch_bounds__(256, 4) void attn_mask_gen_kernel(const MaskGenParams P) {
     const int layer = blockIdx.y;
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -100,43 +109,20 @@ __global__ __launch_bounds__(256, 4) void attn_mask_gen_kernel(const MaskGenPara
     DropCfg base; base.thr16 = P.thr16; base.scale = 1.f; base.s0 = P.s0[layer]; base.s1 = P.s1[layer];
     const DropCfg dc = drop_substream(base, (uint32_t)bh);
     uint32_t W[32];
-    attn_keep_block(dc, (uint32_t)(qt * P.nt + kt), W);
-    store_block(P.mq + (size_t)layer * P.layer_words + ((size_t)bh * per_bh + (size_t)qt * P.nt + kt) * 32, W);
-    transpose32(W);                        // W[query] bit key
-    store_block(P.mk + (size_t)layer * P.layer_words + ((size_t)bh * per_bh + (size_t)kt * P.nt + qt) * 32, W);
+    attn_keep_block(dc, (uint32_t)(qt * P.nt + kt), W);                    // W[key] bit query
+    // key on the lane: lane-side index = key, its row = W[key] (bits over the queries = the register side)
+    store_lane_block(P.lk + (size_t)layer * P.layer_words + ((size_t)bh * per_bh + (size_t)kt * P.nt + qt) * 64, W);
+    transpose32(W);                                                        // W[query] bit key
+    store_lane_block(P.lq + (size_t)layer * P.layer_words + ((size_t)bh * per_bh + (size_t)qt * P.nt + kt) * 64, W);
 }
 
-__host__ inline size_t attn_mask_layer_words(int nbh, int nt) { return (size_t)nbh * nt * nt * MMT_MASK_BLOCK_WORDS; }
+__host__ inline size_t attn_mask_layer_words(int nbh, int nt) { return (size_t)nbh * nt * nt * 64; }      // uint16 words per layer and orientation
 
 // ---- consumer side -------------------------------------------------------------------------------------------------
-typedef const __attribute__((address_space(4))) uint64_t* mask_cptr;       // constant address space: uniform loads become s_load
-struct TileMask { uint64_t m[16]; };
-// the 16 lane masks of block `blk` of a row of blocks starting at `row` (64-bit words, 16 per block); `row` must be wave-uniform
-__device__ __forceinline__ TileMask load_tile_mask(const uint64_t* row, int blk) {
-    TileMask t;
-    mask_cptr p = (mask_cptr)(uintptr_t)(row + (size_t)blk * 16);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t.m[i] = p[i];
-    return t;
-}
-// lane-masked select with the mask in an SGPR pair: mask bit ? v : 0
-__device__ __forceinline__ float keep_sel(float v, uint64_t m) {
-    float r;
-    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
-    return r;
-}
-
-// The same select applied to accumulator registers [i0, i0+8) IN PLACE, for values fresh from v_exp_f32: gfx950 wants one wait
-// state between a transcendental and a VALU instruction that reads its result, and hipcc's hazard recognizer does not look
-// inside asm statements — the leading s_nop supplies it once per eight selects.
-__device__ __forceinline__ void keep_sel8(f32x16& v, int i0, const TileMask& t) {
-    float a0 = v[i0], a1 = v[i0 + 1], a2 = v[i0 + 2], a3 = v[i0 + 3], a4 = v[i0 + 4], a5 = v[i0 + 5], a6 = v[i0 + 6], a7 = v[i0 + 7];
-    asm("s_nop 0\n\t"
-        "v_cndmask_b32 %0, 0, %0, %8\n\tv_cndmask_b32 %1, 0, %1, %9\n\tv_cndmask_b32 %2, 0, %2, %10\n\tv_cndmask_b32 %3, 0, %3, %11\n\t"
-        "v_cndmask_b32 %4, 0, %4, %12\n\tv_cndmask_b32 %5, 0, %5, %13\n\tv_cndmask_b32 %6, 0, %6, %14\n\tv_cndmask_b32 %7, 0, %7, %15"
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
-        : "s"(t.m[i0]), "s"(t.m[i0 + 1]), "s"(t.m[i0 + 2]), "s"(t.m[i0 + 3]), "s"(t.m[i0 + 4]), "s"(t.m[i0 + 5]), "s"(t.m[i0 + 6]), "s"(t.m[i0 + 7]));
-    v[i0] = a0; v[i0 + 1] = a1; v[i0 + 2] = a2; v[i0 + 3] = a3; v[i0 + 4] = a4; v[i0 + 5] = a5; v[i0 + 6] = a6; v[i0 + 7] = a7;
+// all-ones where bit i of the lane's tile word is set (kept), zero where it is clear (dropped): v_bfe_i32
+__device__ __forceinline__ uint32_t keep_bits(uint32_t w, int i) { return (uint32_t)__builtin_amdgcn_sbfe((int)w, i, 1); }
+__device__ __forceinline__ float keep_and(float v, uint32_t w, int i) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & keep_bits(w, i));
 }
 
 // ---- test hook: expand the generator's decisions to one byte per (bh, query, key) ------------------------------------

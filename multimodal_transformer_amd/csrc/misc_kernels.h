@@ -385,3 +385,33 @@ __global__ __launch_bounds__(1024) void ln_param_finalize_kernel(const float* __
         (which ? out_a : out_b)[c] = t;
     }
 }
+
+
+// Concordance correlation coefficient of one sequence per workgroup (transformer/SFT/train.py:42-50): population moments over the
+// first lengths[b] windows, fp64 accumulation, fixed-order tree reduction (deterministic).
+__global__ __launch_bounds__(256) void ccc_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                  const int* __restrict__ lengths, double* __restrict__ out, int T) {
+    __shared__ double red[5][256];
+    const int b = blockIdx.x, n = lengths[b];
+    const float* p = pred + (size_t)b * T;
+    const float* t = target + (size_t)b * T;
+    double sp = 0, st = 0, spp = 0, stt = 0, spt = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double a = p[i], c = t[i];
+        sp += a; st += c; spp += a * a; stt += c * c; spt += a * c;
+    }
+    red[0][threadIdx.x] = sp; red[1][threadIdx.x] = st; red[2][threadIdx.x] = spp; red[3][threadIdx.x] = stt; red[4][threadIdx.x] = spt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double N = (double)n, mp = red[0][0] / N, mt = red[1][0] / N;
+        const double vp = red[2][0] / N - mp * mp, vt = red[3][0] / N - mt * mt, cov = red[4][0] / N - mp * mt;
+        out[b] = (n < 2) ? __builtin_nan("") : 2.0 * cov / (vt + vp + (mp - mt) * (mp - mt));
+    }
+}

@@ -200,3 +200,54 @@ def test_multi_transformer_golden(dev):
     lengths = list(fx["lengths"])
     ins = {m: R.gen_normal("model_mft:" + m, (4, 50, R.EMBED_AVL[m]), R.SEED).to(dev) for m in mods}
     _check_model(dev, fx, model, lambda mask: model(ins, mask, lengths), "model_mft_avl", lengths, 50)
+
+
+def test_batched_ccc_on_device(dev):
+    """device-side per-sequence CCC (mmt_ccc_forward) vs the values the reference's eval_ccc gave for the same rows
+    (fixture `batching`, generated from transformer/SFT/train.py:42-50) and vs the numpy restatement at a large size"""
+    fx = load_golden("batching")
+    mt = mta()
+    lengths = [int(v) for v in fx["lengths"]]
+    pred, tgt = torch.from_numpy(fx["ccc:pred"]).to(dev), torch.from_numpy(fx["in:target"]).to(dev)
+    got = mt.batched_ccc(pred.unsqueeze(2), tgt.unsqueeze(2), lengths).cpu().numpy()
+    ref = fx["ccc:full"]
+    for g, r, L in zip(got, ref, lengths):
+        if L < 2:
+            assert np.isnan(g)
+        else:
+            assert abs(g - r) < 1e-6 * max(1.0, abs(r)), (g, r)
+    B, T = 64, 1000
+    p = R.gen_uniform("ccc:p", (B, T), 3)
+    t = (0.6 * p + 0.4 * R.gen_uniform("ccc:t", (B, T), 3))
+    ls = [T - 13 * i for i in range(B)]
+    got = mt.batched_ccc(p.to(dev), t.to(dev), ls).cpu().numpy()
+    for b in range(B):
+        assert abs(got[b] - mt.eval_ccc(t[b, :ls[b]].numpy(), p[b, :ls[b]].numpy())) < 1e-9
+
+
+def test_evaluate_loop_matches_per_sequence_oracle(dev):
+    """batching.evaluate: batches through the SFT model + device CCC = mean of per-sequence CCCs of the oracle's valence"""
+    from multimodal_transformer_amd import batching
+    MT = mta().multiTransformer
+    model = MT.NLPTransformer(512, embed_dim=40, h=4, N=2, device=dev)
+    p32 = _load_into(model, 19)
+    model = model.to(dev).eval()
+    n, T = 7, 30
+    lengths = [30, 12, 25, 30, 2, 17, 9]
+    x = torch.tanh(R.gen_normal("evalloop:x", (n, T, 512), 19))
+    tgt = R.gen_uniform("evalloop:t", (n, T), 19)
+
+    class Wrap(torch.nn.Module):                        # evaluate() calls model(data_dict, lengths, mask) like the reference's wrapper
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, data, lengths, mask):
+            return self.m(data["fused"], mask, lengths)
+
+    stats = batching.evaluate(Wrap(model), {"fused": x.numpy()}, tgt.numpy(), lengths, batch_size=3, device=dev)
+    cccs = []
+    for i, L in enumerate(lengths):
+        yo = oracle.nlp_transformer(p32, x[i:i + 1, :L], R.prefix_mask([L], L), 4)[0, :, 0].detach().numpy()
+        cccs.append(mta().eval_ccc(yo, tgt[i, :L].numpy()))
+    assert abs(stats["ccc"] - float(np.mean(cccs))) < 2e-3
