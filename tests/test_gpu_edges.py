@@ -11,7 +11,7 @@ from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
 OUT_RTOL = 2e-2
-RELU_GRAD_RTOL = 1.2e-1
+RELU_GRAD_RTOL = 9e-2
 
 
 @pytest.fixture(scope="module")

@@ -22,7 +22,7 @@ from conftest import rel_l2
 pytestmark = pytest.mark.gpu
 
 OUT_RTOL = 2e-2
-RELU_GRAD_RTOL = 1.2e-1
+RELU_GRAD_RTOL = 9e-2
 CCC_MIN = 1 - 1e-3
 
 FULL = {

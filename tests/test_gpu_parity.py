@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 
 OUT_RTOL = 2e-2
 GRAD_RTOL = 4e-2
-RELU_GRAD_RTOL = 1.2e-1
+RELU_GRAD_RTOL = 9e-2          # measured worst over the suite 6.5e-2 (ffn_d128 dw_1.bias), x 1.3
 CCC_MIN = 1 - 1e-3
 
 

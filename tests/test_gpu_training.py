@@ -68,7 +68,7 @@ def test_adam_steps_follow_the_oracle(dev):
         ups_o.append((q.detach() - p32[n]).reshape(-1))
     dist = rel_l2(torch.cat(ups).numpy(), torch.cat(ups_o).numpy())
     print("relative distance between the two accumulated updates: %.3e" % dist)
-    assert dist < 0.25        # measured 0.14: Adam turns small gradient differences of small gradients into full-size steps
+    assert dist < 0.18        # measured 0.138 (x1.3): Adam turns small gradient differences of small gradients into full-size steps
 
 
 def test_loss_decreases_in_train_mode(dev):
