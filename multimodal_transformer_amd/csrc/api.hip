@@ -118,7 +118,7 @@ static int make_dims(EncDims& D, int B, int T, int d, int h, int f, int N) {
     D.Tp = round_up(T, 32); D.nt = D.Tp / 32; D.G = (D.M + 31) / 32; D.GR = (D.M + MMT_ROWS - 1) / MMT_ROWS;
     D.L = make_layout(d, f, h);
     // weight-gradient split over windows: ONE launch covers every layer.  The launch deals (layer, split) units of `tpl` tiles
-    // round-robin to the 8 XCDs (wgrad_kernel), and an XCD holds 32 CUs x 4 workgroups (36 KB of LDS each) at a time: pick the
+    // round-robin to the 8 XCDs (wgrad_kernel), and an XCD holds 32 CUs x 3 workgroups (48 KB of LDS each) at a time: pick the
     // split count that minimises (dispatch rounds on the fullest XCD) x (64-window chunks per workgroup + overhead).
     const LayerLayout& L = D.L;
     const int tpl = (L.NQ / 64) * (L.DP / 64) + (L.DP / 64) * (L.HDP / 64) + 2 * (L.FP / 64) * (L.DP / 64);
@@ -128,7 +128,7 @@ static int make_dims(EncDims& D, int B, int T, int d, int h, int f, int N) {
         const int chunks = (round_up((D.MP + s2 - 1) / s2, 64)) / 64;
         const int per_xcd = (nl * s2 + 7) / 8 * tpl;
         // per workgroup ~4 chunk-times of prologue/slab store; per extra split ~0.7 chunk-times in the slab sums (measured, C4/C3e)
-        const long cost = (long)((per_xcd + 127) / 128) * (chunks + 4) * 10 + 7 * s2;
+        const long cost = (long)((per_xcd + 95) / 96) * (chunks + 4) * 10 + 7 * s2;
         if (best < 0 || cost < best) { best = cost; s = s2; }
     }
     D.mchunk = round_up((D.MP + s - 1) / s, 64);
@@ -138,9 +138,9 @@ static int make_dims(EncDims& D, int B, int T, int d, int h, int f, int N) {
 
 struct LayerWs {
     float *xout, *x1, *stats1, *stats2, *lse;
-    bf16 *xn1T, *xn2T, *QR, *KR, *VR, *QT, *KT, *VT, *ctx, *ctxT, *hid, *hidT;
-    // backward operands of the weight-gradient GEMMs, kept per layer so ONE batched launch forms every layer's dW
-    bf16 *dx2T, *dhT, *dx1T, *dqkvT;
+    bf16 *xn1, *xn2, *QR, *KR, *VR, *QT, *KT, *VT, *ctx, *hid;      // xn1, xn2, ctx, hid: row-major [MP][pad], operands of wgrad
+    // backward operands of the weight-gradient GEMMs (row-major bf16 [MP][pad]), kept per layer so ONE batched launch forms every layer's dW
+    bf16 *dx2, *dh, *dx1, *dqkv;
     float *lnpart1, *lnpart2;
     uint16_t *maskQ, *maskK;                // attention-dropout lane words of this layer (attn_mask.h)
 };
@@ -149,7 +149,7 @@ struct EncWs {
     LayerWs lw[MAX_LAYERS];
     // backward scratch (shared by all layers; single stream)
     float *dxa, *dxb, *delta, *lnpartf;
-    bf16 *dh, *dOR, *dOT, *dqkv;
+    bf16 *dOR, *dOT;
     float *sWqkv, *sbqkv, *sWo, *sbo, *sW1, *sb1, *sW2, *sb2;   // slab sets of layer 0; layer l at + l * slab_stride
     size_t slab_stride;
     size_t bytes;
@@ -167,15 +167,14 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
         w.xout = c.take<float>(M * D.d); w.x1 = c.take<float>(M * D.d);
         w.stats1 = c.take<float>(2 * M); w.stats2 = c.take<float>(2 * M);
         w.lse = c.take<float>(BH * D.Tp);
-        w.xn1T = c.take<bf16>((size_t)L.DP * MP); w.xn2T = c.take<bf16>((size_t)L.DP * MP);
+        w.xn1 = c.take<bf16>(MP * L.DP); w.xn2 = c.take<bf16>(MP * L.DP);          // MP rows: rows >= M stay zero for wgrad
         w.QR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); w.KR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP));
         w.VR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP));
         w.QT = c.take<bf16>(BH * fragT_elems(D.Tp)); w.KT = c.take<bf16>(BH * fragT_elems(D.Tp));
         w.VT = c.take<bf16>(BH * fragT_elems(D.Tp));
-        w.ctx = c.take<bf16>(M * L.HDP); w.ctxT = c.take<bf16>((size_t)L.HDP * MP);
-        w.hid = c.take<bf16>(M * L.FP); w.hidT = c.take<bf16>((size_t)L.FP * MP);
-        w.dx2T = c.take<bf16>((size_t)L.DP * MP); w.dhT = c.take<bf16>((size_t)L.FP * MP);
-        w.dx1T = c.take<bf16>((size_t)L.DP * MP); w.dqkvT = c.take<bf16>((size_t)L.NQ * MP);
+        w.ctx = c.take<bf16>(MP * L.HDP); w.hid = c.take<bf16>(MP * L.FP);
+        w.dx2 = c.take<bf16>(MP * L.DP); w.dh = c.take<bf16>(MP * L.FP);
+        w.dx1 = c.take<bf16>(MP * L.DP); w.dqkv = c.take<bf16>(MP * L.NQ);
     }
     {   // attention-dropout bit masks: [layer][bh][tile][tile][32 words], both orientations, written by ONE generator launch
         const size_t lw = attn_mask_layer_words(D.B * D.h, D.nt);
@@ -189,9 +188,7 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
     W.dxa = c.take<float>(M * D.d); W.dxb = c.take<float>(M * D.d);
     W.delta = c.take<float>(BH * D.Tp);
     W.lnpartf = c.take<float>((size_t)D.G * 2 * L.DP);
-    W.dh = c.take<bf16>(M * L.FP);
     W.dOR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); W.dOT = c.take<bf16>(BH * fragT_elems(D.Tp));
-    W.dqkv = c.take<bf16>(M * L.NQ);
     const size_t S = D.nsplit;
     {   // one slab set per layer, identical sizes: layer l's set lives at + l * slab_stride floats
         const size_t before = c.off;
@@ -297,7 +294,7 @@ template <typename K> static int allow_big_lds(K kernel, int static_lds) {
 }
 
 // `drop`: the layer's attention dropout (thr16 == 0: off); maskQ: its lane words, written by launch_mask_gen
-static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* VT, bf16* ctx, bf16* ctxT, float* lse,
+static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* VT, bf16* ctx, float* lse,
                            const EncDims& D, hipStream_t st, DropCfg drop = no_drop(), const uint16_t* maskQ = nullptr) {
     dim3 grid(attn_grid((D.nt + 3) / 4, D.B * D.h));
     if (drop.thr16 && !maskQ) return fail(MMT_EINVAL, "attention dropout without a mask buffer");
@@ -310,12 +307,12 @@ static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* 
     }
     const size_t bal = balance_lds((int)grid.x, (size_t)2 * (DKP * 4 + 128) * 16);
     ProfScope prof(S_ATTN_FWD, st);
-#define MMT_FWD(dkp, dr) hipLaunchKernelGGL((attn_fwd_kernel<dkp, dr>), grid, dim3(MMT_THREADS), bal, st, QR, KR, VT, ctx, ctxT, lse, \
-                                            D.h, D.T, D.nt, D.B * D.h, D.L.HDP, D.MP, maskQ, drop.scale)
+#define MMT_FWD(dkp, dr) hipLaunchKernelGGL((attn_fwd_kernel<dkp, dr>), grid, dim3(MMT_THREADS), bal, st, QR, KR, VT, ctx, lse, \
+                                            D.h, D.T, D.nt, D.B * D.h, D.L.HDP, maskQ, drop.scale)
 #ifdef MMT_ABLATIONS
     static const int abl = getenv("MMT_ABL") ? atoi(getenv("MMT_ABL")) : 0;
-#define MMT_FWD_A(a) hipLaunchKernelGGL((attn_fwd_kernel<16, true, a>), grid, dim3(MMT_THREADS), (a == 6 ? (allow_big_lds(&attn_fwd_kernel<16, true, 6>, 6144), bal) : 0), st, QR, KR, VT, ctx, ctxT, lse, \
-                                        D.h, D.T, D.nt, D.B * D.h, D.L.HDP, D.MP, maskQ, drop.scale)
+#define MMT_FWD_A(a) hipLaunchKernelGGL((attn_fwd_kernel<16, true, a>), grid, dim3(MMT_THREADS), (a == 6 ? (allow_big_lds(&attn_fwd_kernel<16, true, 6>, 6144), bal) : 0), st, QR, KR, VT, ctx, lse, \
+                                        D.h, D.T, D.nt, D.B * D.h, D.L.HDP, maskQ, drop.scale)
     if (abl && DKP == 16 && drop.thr16) {
         switch (abl) { case 1: MMT_FWD_A(1); break; case 2: MMT_FWD_A(2); break; case 3: MMT_FWD_A(3); break; case 4: MMT_FWD_A(4); break;
                        case 5: MMT_FWD_A(5); break; default: MMT_FWD_A(6); }
@@ -329,10 +326,10 @@ static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* 
     return MMT_OK;
 }
 
-// dQ, dK, dV -> bf16 row-major dqkv [M][NQ] (columns: dQ | dK | dV, heads padded) and its T layout [NQ][MP]
+// dQ, dK, dV -> bf16 row-major dqkv [M][NQ] (columns: dQ | dK | dV, heads padded)
 static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* KR, const bf16* KT_, const bf16* VR,
                            const bf16* dOR, const bf16* dOT, const float* lse, const float* delta, const float* rowmask,
-                           bf16* dqkv, bf16* dqkvT, const EncDims& D, hipStream_t st, DropCfg drop = no_drop(),
+                           bf16* dqkv, const EncDims& D, hipStream_t st, DropCfg drop = no_drop(),
                            const uint16_t* maskQ = nullptr, const uint16_t* maskK = nullptr) {
     dim3 grid(attn_grid((D.nt + 3) / 4, D.B * D.h));
     const float scale = 1.0f / sqrtf((float)D.L.dk);
@@ -347,7 +344,7 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
         }
         ProfScope prof(S_ATTN_BWD_FUSED, st);
 #define MMT_FUSED(dr) hipLaunchKernelGGL((attn_bwd_fused16_kernel<dr>), dim3(D.B * D.h), dim3(MMT_FUSED_THREADS), MMT_FUSED_LDS_BYTES, st, \
-                                          QR, QT, KR, KT_, VR, dOR, dOT, lse, delta, rowmask, scale, dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, maskK, drop.scale)
+                                          QR, QT, KR, KT_, VR, dOR, dOT, lse, delta, rowmask, scale, dqkv, D.L.NQ, D.h, D.T, D.nt, maskK, drop.scale)
         if (drop.thr16) MMT_FUSED(true); else MMT_FUSED(false);
 #undef MMT_FUSED
         LAUNCH_CHECK("attn_bwd_fused16_kernel");
@@ -356,7 +353,7 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
     {
         ProfScope prof(S_ATTN_BWD, st);
 #define MMT_DKV(dkp, dr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, QT, KR, VR, dOR, dOT, lse, delta, \
-                                            dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, D.B * D.h, maskK, drop.scale)
+                                            dqkv, D.L.NQ, D.h, D.T, D.nt, D.B * D.h, maskK, drop.scale)
         if (DKP == 16) { if (drop.thr16) MMT_DKV(16, true); else MMT_DKV(16, false); }
         else { if (drop.thr16) MMT_DKV(32, true); else MMT_DKV(32, false); }
 #undef MMT_DKV
@@ -365,7 +362,7 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
     {
         ProfScope prof(S_ATTN_BWD_DQ, st);
 #define MMT_DQ(dkp, dr) hipLaunchKernelGGL((attn_bwd_dq_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, KT_, VR, dOR, lse, delta, rowmask, \
-                                           scale, dqkv, D.L.NQ, dqkvT, D.MP, D.h, D.T, D.nt, D.B * D.h, maskQ, drop.scale)
+                                           scale, dqkv, D.L.NQ, D.h, D.T, D.nt, D.B * D.h, maskQ, drop.scale)
         if (DKP == 16) { if (drop.thr16) MMT_DQ(16, true); else MMT_DQ(16, false); }
         else { if (drop.thr16) MMT_DQ(32, true); else MMT_DQ(32, false); }
 #undef MMT_DQ
@@ -434,7 +431,7 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
             const float* Pl = params + (size_t)ll * L.stride();
             RowGemmParams p = rg_zero();
             p.M = D.M; p.K = d; p.KP = L.DP; p.N = 3 * L.HD; p.NP = L.NQ;
-            p.A = src; p.lda = d; p.At_out = wl.xn1T; p.ldt = D.MP;
+            p.A = src; p.lda = d; p.A_out = wl.xn1; p.lda_out = L.DP;
             p.ln_a = Pl + L.oln(0); p.ln_b = Pl + L.oln(1); p.eps = eps; p.stats = wl.stats1;
             p.W = W.wprep + (size_t)ll * L.pstride() + L.pWqkv(); p.bias = W.bprep + (size_t)ll * L.qstride() + L.qbqkv();
             p.fragR[0] = wl.QR; p.fragR[1] = wl.KR; p.fragR[2] = wl.VR;
@@ -448,7 +445,7 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
             if ((rc = launch_rowgemm<EPI_FRAG, true>(p, st, S_LN1_QKV))) return rc;
         }
         // dropout streams of layer l: 4l+0 attention probabilities (:33), 4l+1 / 4l+3 sublayer outputs (:104), 4l+2 FFN hidden (:20)
-        if ((rc = launch_attn_fwd(L.DKP, w.QR, w.KR, w.VT, w.ctx, w.ctxT, w.lse, D, st, make_drop(dropout_p, seed, 4 * l + 0), w.maskQ))) return rc;
+        if ((rc = launch_attn_fwd(L.DKP, w.QR, w.KR, w.VT, w.ctx, w.lse, D, st, make_drop(dropout_p, seed, 4 * l + 0), w.maskQ))) return rc;
         {   // out-proj + residual -> LN2 + FFN1 + ReLU -> FFN2 + residual, one kernel, x1 and hid stay in LDS
             RowChain3 ch; memset(&ch, 0, sizeof(ch));
             {   RowGemmParams& p = ch.a; p = rg_zero();
@@ -459,10 +456,10 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
                 p.drop = make_drop(dropout_p, seed, 4 * l + 1); }
             {   RowGemmParams& p = ch.b; p = rg_zero();
                 p.M = D.M; p.K = d; p.KP = L.DP; p.N = f; p.NP = L.FP;
-                p.At_out = w.xn2T; p.ldt = D.MP;
+                p.A_out = w.xn2; p.lda_out = L.DP;
                 p.ln_a = P + L.oln(2); p.ln_b = P + L.oln(3); p.eps = eps; p.stats = w.stats2;
                 p.W = wp + L.pW1(); p.bias = bp + L.qb1(); p.act = 1;
-                p.out_bf16 = w.hid; p.ldo16 = L.FP; p.n_store16 = L.FP; p.out_T = w.hidT; p.ldoT = D.MP;
+                p.out_bf16 = w.hid; p.ldo16 = L.FP; p.n_store16 = L.FP;
                 p.drop = make_drop(dropout_p, seed, 4 * l + 2); }
             {   RowGemmParams& p = ch.c; p = rg_zero();
                 p.M = D.M; p.K = L.FP; p.KP = L.FP; p.N = d; p.NP = L.DP;
@@ -539,9 +536,9 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
     WgradJobs J; memset(&J, 0, sizeof(J));
     J.MP = D.MP; J.M16 = D.M16; J.mchunk = D.mchunk;
     int t0 = 0;
-    auto add_job = [&](const bf16* At, const bf16* Bt, float* out, float* bout, int NPj, int KPj) {
+    auto add_job = [&](const bf16* A, int lda, const bf16* B_, int ldb, float* out, float* bout, int NPj, int KPj) {
         WgradJob& j = J.j[J.njobs++];
-        j.At = At; j.Bt = Bt; j.out = out; j.bias_out = bout;
+        j.A = A; j.lda = lda; j.B = B_; j.ldb = ldb; j.out = out; j.bias_out = bout;
         j.NPj = NPj; j.KPj = KPj; j.tile0 = t0; j.tiles_k = KPj / 64;
         t0 += (NPj / 64) * (KPj / 64);
     };
@@ -554,22 +551,22 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
         const float* xin = (l > 0) ? W.lw[l - 1].xout : x;
         {   // dx2 -> dh -> dx1 -> dO fragments, one kernel; dh and dx1 stay in LDS
             RowChain3 ch; memset(&ch, 0, sizeof(ch));
-            {   RowGemmParams& p = ch.a; p = rg_zero();           // dh = (drop'(dx2) W2) * relu'(hid)   [emits dx2^T, dh^T]
+            {   RowGemmParams& p = ch.a; p = rg_zero();           // dh = (drop'(dx2) W2) * relu'(hid)   [emits dx2, dh as bf16 rows]
                 p.M = D.M; p.K = d; p.KP = L.DP; p.N = f; p.NP = L.FP;
-                p.A = cur; p.lda = d; p.At_out = w.dx2T; p.ldt = D.MP;
+                p.A = cur; p.lda = d; p.A_out = w.dx2; p.lda_out = L.DP;
                 p.W = wp + L.pW2T();
                 p.relu_mask = w.hid; p.ldm = L.FP;          // hid > 0  <=>  ReLU passed AND the unit was kept
                 p.mask_scale = make_drop(dropout_p, seed, 4 * l + 2).scale;
                 p.a_drop = make_drop(dropout_p, seed, 4 * l + 3);   // gradient of the dropped sublayer-1 output
-                p.out_T = w.dhT; p.ldoT = D.MP; }
+                p.out_bf16 = w.dh; p.ldo16 = L.FP; p.n_store16 = L.FP; }
             {   RowGemmParams& p = ch.b; p = rg_zero();           // dx1 = dx2 + LN2bwd(dh W1)
                 p.M = D.M; p.K = L.FP; p.KP = L.FP; p.N = d; p.NP = L.DP;
                 p.W = wp + L.pW1T();
                 p.x = w.x1; p.ldx = d; p.st = w.stats2; p.ln_a = P + L.oln(2); p.eps = eps; p.d_real = d;
                 p.dres = cur; p.lddres = d; p.out_f32 = other; p.ldo = d; p.colpart = w.lnpart2; }
-            {   RowGemmParams& p = ch.c; p = rg_zero();           // dO = drop'(dx1) Wo -> fragments + delta   [emits dx1^T]
+            {   RowGemmParams& p = ch.c; p = rg_zero();           // dO = drop'(dx1) Wo -> fragments + delta   [emits dx1 as bf16 rows]
                 p.M = D.M; p.K = d; p.KP = L.DP; p.N = L.HD; p.NP = L.HDP;
-                p.At_out = w.dx1T; p.ldt = D.MP;
+                p.A_out = w.dx1; p.lda_out = L.DP;
                 p.W = wp + L.pWoT();
                 p.a_drop = make_drop(dropout_p, seed, 4 * l + 1);   // gradient of the dropped sublayer-0 output
                 p.fragR[0] = W.dOR; p.fragT[0] = W.dOT;
@@ -579,12 +576,12 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             if ((rc = launch_rowchain(encoder_pre_attn_bwd_kernel, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st))) return rc;
         }
         if ((rc = launch_attn_bwd(L.DKP, w.QR, w.QT, w.KR, w.KT, w.VR, W.dOR, W.dOT, w.lse, W.delta, mask,
-                                  W.dqkv, w.dqkvT, D, st, make_drop(dropout_p, seed, 4 * l + 0), w.maskQ, w.maskK))) return rc;
+                                  w.dqkv, D, st, make_drop(dropout_p, seed, 4 * l + 0), w.maskQ, w.maskK))) return rc;
         float* dxin = (l > 0) ? cur : dx;
         {   // dx = dx1 + LN1bwd(dQKV Wqkv)
             RowGemmParams p = rg_zero();
             p.M = D.M; p.K = L.NQ; p.KP = L.NQ; p.N = d; p.NP = L.DP;
-            p.A = W.dqkv; p.a_bf16 = 1; p.lda = L.NQ;
+            p.A = w.dqkv; p.a_bf16 = 1; p.lda = L.NQ;
             p.W = wp + L.pWqkvT();
             p.x = xin; p.ldx = d; p.st = w.stats1; p.ln_a = P + L.oln(0); p.eps = eps; p.d_real = d;
             p.dres = other; p.lddres = d; p.out_f32 = dxin; p.ldo = d; p.colpart = w.lnpart1;
@@ -592,10 +589,10 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
         }
         // weight-gradient jobs of this layer (run later, all layers in one launch)
         const size_t so = (size_t)l * W.slab_stride;
-        add_job(w.dqkvT, w.xn1T, W.sWqkv + so, W.sbqkv + so, L.NQ, L.DP);
-        add_job(w.dx1T, w.ctxT, W.sWo + so, W.sbo + so, L.DP, L.HDP);
-        add_job(w.dhT, w.xn2T, W.sW1 + so, W.sb1 + so, L.FP, L.DP);
-        add_job(w.dx2T, w.hidT, W.sW2 + so, W.sb2 + so, L.DP, L.FP);
+        add_job(w.dqkv, L.NQ, w.xn1, L.DP, W.sWqkv + so, W.sbqkv + so, L.NQ, L.DP);
+        add_job(w.dx1, L.DP, w.ctx, L.HDP, W.sWo + so, W.sbo + so, L.DP, L.HDP);
+        add_job(w.dh, L.FP, w.xn2, L.DP, W.sW1 + so, W.sb1 + so, L.FP, L.DP);
+        add_job(w.dx2, L.DP, w.hid, L.FP, W.sW2 + so, W.sb2 + so, L.DP, L.FP);
         // cur now holds dx of this layer (= dx2 of the layer below); `other` is free again
     }
     if (D.N > 0) {
@@ -689,7 +686,7 @@ __global__ void unpad_heads_kernel(const bf16* __restrict__ src, int ld, int col
     }
 }
 
-struct SdpaWs { bf16 *QR, *QT, *KR, *KT, *VR, *VT, *dOR, *dOT, *ctx, *ctxT, *dqkv, *dqkvT; float *lse, *delta; uint16_t *maskQ, *maskK; size_t bytes; };
+struct SdpaWs { bf16 *QR, *QT, *KR, *KT, *VR, *VT, *dOR, *dOT, *ctx, *dqkv; float *lse, *delta; uint16_t *maskQ, *maskK; size_t bytes; };
 static void carve_sdpa(SdpaWs& W, const EncDims& D, void* base) {
     Carver c(base);
     const LayerLayout& L = D.L;
@@ -697,8 +694,8 @@ static void carve_sdpa(SdpaWs& W, const EncDims& D, void* base) {
     bf16** r[] = {&W.QR, &W.KR, &W.VR, &W.dOR};
     bf16** t[] = {&W.QT, &W.KT, &W.VT, &W.dOT};
     for (int i = 0; i < 4; ++i) { *r[i] = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); *t[i] = c.take<bf16>(BH * fragT_elems(D.Tp)); }
-    W.ctx = c.take<bf16>(M * L.HDP); W.ctxT = c.take<bf16>((size_t)L.HDP * D.MP);
-    W.dqkv = c.take<bf16>(M * L.NQ); W.dqkvT = c.take<bf16>((size_t)L.NQ * D.MP);
+    W.ctx = c.take<bf16>(M * L.HDP);
+    W.dqkv = c.take<bf16>(M * L.NQ);
     W.lse = c.take<float>(BH * D.Tp); W.delta = c.take<float>(BH * D.Tp);
     W.maskQ = c.take<uint16_t>(attn_mask_layer_words(D.B * D.h, D.nt)); W.maskK = c.take<uint16_t>(attn_mask_layer_words(D.B * D.h, D.nt));
     W.bytes = c.off;
@@ -736,7 +733,7 @@ extern "C" int mmt_sdpa_forward(const float* q, const float* k, const float* v, 
     hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, v, W.VR, W.VT, nullptr, 1.f, 0, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
     LAUNCH_CHECK("pack_frag_kernel");
     if (dropout_p > 0.f && (rc = launch_mask_gen(W.maskQ, W.maskK, D, 1, dropout_p, seed, st))) return rc;
-    if ((rc = launch_attn_fwd(L.DKP, W.QR, W.KR, W.VT, W.ctx, W.ctxT, W.lse, D, st, make_drop(dropout_p, seed, 0), W.maskQ))) return rc;
+    if ((rc = launch_attn_fwd(L.DKP, W.QR, W.KR, W.VT, W.ctx, W.lse, D, st, make_drop(dropout_p, seed, 0), W.maskQ))) return rc;
     hipLaunchKernelGGL(unpad_heads_kernel, dim3(grid_for((size_t)D.M * d)), dim3(256), 0, st, W.ctx, L.HDP, 0, ctx, D.M, h, L.dk, L.DKP, d);
     LAUNCH_CHECK("unpad_heads_kernel");
     return MMT_OK;
@@ -757,7 +754,7 @@ extern "C" int mmt_sdpa_backward(const float* dctx, const float* mask, float* dq
     hipLaunchKernelGGL(pack_frag_kernel, dim3(grid_for((size_t)D.M * h)), dim3(256), 0, st, dctx, W.dOR, W.dOT, nullptr, 1.f, 0,
                        W.ctx, L.HDP, W.delta, D.M, T, D.Tp, h, L.dk, L.DKP, d);
     LAUNCH_CHECK("pack_frag_kernel");
-    if ((rc = launch_attn_bwd(L.DKP, W.QR, W.QT, W.KR, W.KT, W.VR, W.dOR, W.dOT, W.lse, W.delta, mask, W.dqkv, W.dqkvT, D, st,
+    if ((rc = launch_attn_bwd(L.DKP, W.QR, W.QT, W.KR, W.KT, W.VR, W.dOR, W.dOT, W.lse, W.delta, mask, W.dqkv, D, st,
                               make_drop(dropout_p, seed, 0), W.maskQ, W.maskK))) return rc;     // the masks the forward generated
     const int g = grid_for((size_t)D.M * d);
     hipLaunchKernelGGL(unpad_heads_kernel, dim3(g), dim3(256), 0, st, W.dqkv, L.NQ, 0, dq, D.M, h, L.dk, L.DKP, d);
@@ -773,50 +770,43 @@ __global__ void pad_f32_kernel(const float* __restrict__ src, float* __restrict_
     if (i < np) dst[i] = (i < n && src) ? src[i] : 0.f;
 }
 
-// g = dy * rowscale * act'(y) -> bf16 row-major [M][NP] and T layout [NP][MP].  32x32 tiles through LDS: both outputs are
-// written in contiguous runs (the element-per-thread form wrote the T layout as M*NP separate 2-byte transactions: 31 us per call)
+// g = dy * rowscale * act'(y) -> bf16 row-major [M][NP] (pad columns written as zeros): the A operand of the input-gradient GEMM and
+// of the weight-gradient kernel
 __global__ void grad_prep_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ rowscale,
-                                 int act, bf16* __restrict__ g, bf16* __restrict__ gT, int M, int N, int NP, int MP) {
-    __shared__ float tile[32][33];
-    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 8 rows per pass
-    for (int r = ty; r < 32; r += 8) {
-        const int m = m0 + r, n = n0 + tx;
-        float v = 0.f;
-        if (m < M && n < N) {
-            v = dy[(size_t)m * N + n];
-            if (rowscale) v *= rowscale[m];
-            if (act == 1) { if (!(y[(size_t)m * N + n] > 0.f)) v = 0.f; }
-            else if (act == 2) { const float yy = y[(size_t)m * N + n]; v *= 1.f - yy * yy; }
-            else if (act == 3) { const float yy = y[(size_t)m * N + n]; v *= yy * (1.f - yy); }
+                                 int act, bf16* __restrict__ g, int M, int N, int NP) {
+    const size_t total = (size_t)M * (NP >> 2);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / (NP >> 2)), n = (int)(idx % (NP >> 2)) * 4;
+        bf16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = 0.f;
+            if (n + i < N) {
+                v = dy[(size_t)m * N + n + i];
+                if (rowscale) v *= rowscale[m];
+                if (act == 1) { if (!(y[(size_t)m * N + n + i] > 0.f)) v = 0.f; }
+                else if (act == 2) { const float yy = y[(size_t)m * N + n + i]; v *= 1.f - yy * yy; }
+                else if (act == 3) { const float yy = y[(size_t)m * N + n + i]; v *= yy * (1.f - yy); }
+            }
+            o[i] = (bf16)v;
         }
-        tile[r][tx] = v;
-        if (m < M) g[(size_t)m * NP + n] = (bf16)v;
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int n = n0 + r, m = m0 + tx;
-        if (m < M) gT[(size_t)n * MP + m] = (bf16)tile[tx][r];
+        *reinterpret_cast<bf16x4*>(g + (size_t)m * NP + n) = o;
     }
 }
 
-// fp32 [M][K] -> bf16 T layout [KP][MP] (rows k >= K are written as zeros for m < M)
-__global__ void transpose_cast_kernel(const float* __restrict__ src, bf16* __restrict__ dstT, int M, int K, int KP, int MP) {
-    __shared__ float tile[32][33];
-    const int m0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 8 rows per pass
-    for (int r = ty; r < 32; r += 8) {
-        const int m = m0 + r, k = k0 + tx;
-        tile[r][tx] = (m < M && k < K) ? src[(size_t)m * K + k] : 0.f;
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int k = k0 + r, m = m0 + tx;
-        if (k < KP && m < M) dstT[(size_t)k * MP + m] = (bf16)tile[tx][r];
+// fp32 [M][K] -> bf16 row-major [M][KP] (pad columns written as zeros): the B operand of the weight-gradient kernel
+__global__ void cast_rows_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int M, int K, int KP) {
+    const size_t total = (size_t)M * (KP >> 2);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / (KP >> 2)), k = (int)(idx % (KP >> 2)) * 4;
+        bf16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (bf16)((k + i < K) ? src[(size_t)m * K + k + i] : 0.f);
+        *reinterpret_cast<bf16x4*>(dst + (size_t)m * KP + k) = o;
     }
 }
 
-struct LinWs { bf16 *Wp, *WTp, *g, *gT, *xT; float *bp, *sW, *sb; int KP, NP, MP, M16, nsplit, mchunk; size_t bytes; };
+struct LinWs { bf16 *Wp, *WTp, *g, *xb; float *bp, *sW, *sb; int KP, NP, MP, M16, nsplit, mchunk; size_t bytes; };
 static void carve_linear(LinWs& W, int M, int K, int N, void* base) {
     Carver c(base);
     W.KP = round_up(K, 64); W.NP = round_up(N, 64); W.MP = round_up(M, 64); W.M16 = round_up(M, 16);
@@ -826,7 +816,7 @@ static void carve_linear(LinWs& W, int M, int K, int N, void* base) {
     W.nsplit = (W.MP + W.mchunk - 1) / W.mchunk;
     W.Wp = c.take<bf16>((size_t)W.NP * W.KP); W.WTp = c.take<bf16>((size_t)W.KP * W.NP);
     W.bp = c.take<float>(W.NP);
-    W.g = c.take<bf16>((size_t)M * W.NP); W.gT = c.take<bf16>((size_t)W.NP * W.MP); W.xT = c.take<bf16>((size_t)W.KP * W.MP);
+    W.g = c.take<bf16>((size_t)W.MP * W.NP); W.xb = c.take<bf16>((size_t)W.MP * W.KP);      // MP rows: rows >= M stay zero for wgrad
     W.sW = c.take<float>((size_t)W.nsplit * W.NP * W.KP); W.sb = c.take<float>((size_t)W.nsplit * W.NP);
     W.bytes = c.off;
 }
@@ -870,7 +860,7 @@ extern "C" int mmt_linear_backward(const float* dy, const float* x, const float*
     LinWs W; carve_linear(W, M, K, N, workspace);
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(grad_prep_kernel, dim3((M + 31) / 32, W.NP / 32), dim3(256), 0, st, dy, y, rowscale, act, W.g, W.gT, M, N, W.NP, W.MP);
+    hipLaunchKernelGGL(grad_prep_kernel, dim3(grid_for((size_t)M * (W.NP / 4))), dim3(256), 0, st, dy, y, rowscale, act, W.g, M, N, W.NP);
     LAUNCH_CHECK("grad_prep_kernel");
     if (dx) {
         hipLaunchKernelGGL(pad_cast_kernel, dim3(grid_for((size_t)W.KP * W.NP)), dim3(256), 0, st, Wt, W.WTp, K, N, W.KP, W.NP, 1);
@@ -882,11 +872,11 @@ extern "C" int mmt_linear_backward(const float* dy, const float* x, const float*
         if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st, S_LINEAR_BWD_DX))) return rc;
     }
     if (dW || db) {
-        hipLaunchKernelGGL(transpose_cast_kernel, dim3((M + 31) / 32, W.KP / 32), dim3(256), 0, st, x, W.xT, M, K, W.KP, W.MP);
-        LAUNCH_CHECK("transpose_cast_kernel");
+        hipLaunchKernelGGL(cast_rows_kernel, dim3(grid_for((size_t)M * (W.KP / 4))), dim3(256), 0, st, x, W.xb, M, K, W.KP);
+        LAUNCH_CHECK("cast_rows_kernel");
         WgradJobs J; memset(&J, 0, sizeof(J));
         J.njobs = 1; J.MP = W.MP; J.M16 = W.M16; J.mchunk = W.mchunk;
-        J.j[0].At = W.gT; J.j[0].Bt = W.xT; J.j[0].out = W.sW; J.j[0].bias_out = W.sb;
+        J.j[0].A = W.g; J.j[0].lda = W.NP; J.j[0].B = W.xb; J.j[0].ldb = W.KP; J.j[0].out = W.sW; J.j[0].bias_out = W.sb;
         J.j[0].NPj = W.NP; J.j[0].KPj = W.KP; J.j[0].tile0 = 0; J.j[0].tiles_k = W.KP / 64;
         {
             ProfScope prof(S_LINEAR_WGRAD, st);

@@ -118,8 +118,8 @@ __device__ unsigned long long* g_attn_stamps = nullptr;        // [wave id][16]:
 template <int DKP, bool DROP, int ABL = 0>
 __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
         const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vt,
-        bf16* __restrict__ ctx, bf16* __restrict__ ctxT, float* __restrict__ lse,
-        int h, int T, int nt, int nbh, int ldc, int MP, const uint16_t* __restrict__ maskQ, float drop_scale) {
+        bf16* __restrict__ ctx, float* __restrict__ lse,
+        int h, int T, int nt, int nbh, int ldc, const uint16_t* __restrict__ maskQ, float drop_scale) {
     constexpr int KS = DKP / 16;
     constexpr bool ONES = (DKP == 16) && !DROP;        // row sums through the MFMA
 #ifdef MMT_ABLATIONS
@@ -266,8 +266,6 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
             for (int i = 0; i < 4; ++i) v[i] = (bf16)(o[4 * g + i] * inv);
             const int e0 = 8 * g + 4 * hh;
             *reinterpret_cast<bf16x4*>(ctx + m * ldc + head * DKP + e0) = v;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ctxT[(size_t)(head * DKP + e0 + i) * MP + m] = v[i];
         }
     }
 #ifdef MMT_ABLATIONS
@@ -297,7 +295,6 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
         const bf16* __restrict__ dOr, const bf16* __restrict__ dOt,
         const float* __restrict__ lse, const float* __restrict__ delta,
         bf16* __restrict__ dkv, int lddkv,      // row-major [M][lddkv]; dK at column HD, dV at 2*HD
-        bf16* __restrict__ dkvT, int MP,        // T layout  [3*HD rows][MP]
         int h, int T, int nt, int nbh, const uint16_t* __restrict__ maskK, float drop_scale) {
     constexpr int KS = DKP / 16;
     constexpr int PR = DKP * 4, PT = 128, PC = 8;       // pieces: R-layout tile, T-layout tile, 32 fp32 row constants
@@ -434,11 +431,6 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
             const int e0 = head * DKP + 8 * g + 4 * hh;
             *reinterpret_cast<bf16x4*>(dkv + m * lddkv + HD + e0) = kv;
             *reinterpret_cast<bf16x4*>(dkv + m * lddkv + 2 * HD + e0) = vv;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                dkvT[(size_t)(HD + e0 + j) * MP + m] = kv[j];
-                dkvT[(size_t)(2 * HD + e0 + j) * MP + m] = vv[j];
-            }
         }
     }
 }
@@ -453,7 +445,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
         const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Kt, const bf16* __restrict__ Vr,
         const bf16* __restrict__ dOr, const float* __restrict__ lse, const float* __restrict__ delta,
         const float* __restrict__ rowmask, float scale,
-        bf16* __restrict__ dqkv, int lddqkv, bf16* __restrict__ dqkvT, int MP,
+        bf16* __restrict__ dqkv, int lddqkv,
         int h, int T, int nt, int nbh, const uint16_t* __restrict__ maskQ, float drop_scale) {
     constexpr int KS = DKP / 16;
     constexpr int PR = DKP * 4, PT = 128;
@@ -552,8 +544,6 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
             for (int j = 0; j < 4; ++j) v[j] = (bf16)(dq[4 * g + j] * sc);
             const int e0 = head * DKP + 8 * g + 4 * hh;
             *reinterpret_cast<bf16x4*>(dqkv + m * lddqkv + e0) = v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dqkvT[(size_t)(e0 + j) * MP + m] = v[j];
         }
     }
 }

@@ -37,7 +37,6 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
         const bf16* __restrict__ Vr, const bf16* __restrict__ dOr, const bf16* __restrict__ dOt,
         const float* __restrict__ lse, const float* __restrict__ delta, const float* __restrict__ rowmask, float scale,
         bf16* __restrict__ dqkv, int lddkv,     // row-major [M][lddkv]: dQ at column 0, dK at HD, dV at 2*HD
-        bf16* __restrict__ dqkvT, int MP,       // T layout  [3*HD rows][MP]
         int h, int T, int nt, const uint16_t* __restrict__ maskK, float drop_scale) {
     constexpr int DKP = 16, PR = 64, PT = 128, PC = 8, TOTAL = MMT_FUSED_STAGE_PIECES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,14 +101,16 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
     const bool key_tail = live && (kt == nt - 1) && (T & 31);
     const uint32_t kcol = (uint32_t)(kt * 32 + r);
-    // dQ reduction: this lane's output of a tile.  Lanes 0..31: T layout, feature e = wave, query q = lane; lanes 32..63: row-major,
-    // query 2*wave + (lane>>4 & 1), feature lane & 15.  Partial word of (e, q): register (e&3) + 4*(e>>3), lane q + 32*((e>>2)&1).
-    const int oe = hh ? (lane & 15) : wave, oq = hh ? (2 * wave + ((lane >> 4) & 1)) : r;
-    const int poff = ((oe & 3) + 4 * (oe >> 3)) * MMT_FUSED_PART_LD + oq + 32 * ((oe >> 2) & 1);
+    // dQ reduction: the 512 outputs (32 queries x 16 features) of a tile: lanes i and 32 + i of wave w both own query 2w + (i >> 4),
+    // feature i & 15; the lower lane sums the partials of waves 0..7, the upper lane those of waves 8..15, one half-wave exchange
+    // (v_permlane32_swap) adds the two, and the upper lane stores (32 contiguous bytes per query row).  Partial word of (e, q):
+    // register (e&3) + 4*(e>>3), lane q + 32*((e>>2)&1).
+    const int oe = lane & 15, oq = 2 * wave + ((lane >> 4) & 1);
+    const int poff = ((oe & 3) + 4 * (oe >> 3)) * MMT_FUSED_PART_LD + oq + 32 * ((oe >> 2) & 1) + hh * 8 * (2 * MMT_FUSED_REGION_BYTES / 4);
     const float* const pbase = reinterpret_cast<const float*>(reg0) + poff;
-    // its destination is linear in the tile index: element offsets from dqkv (row-major half) or dqkvT, and the step per tile
+    // its destination is linear in the tile index: element offset from dqkv and the step per tile
     const uint32_t m0 = (uint32_t)b * (uint32_t)T;
-    uint32_t doff = hh ? ((m0 + oq) * (uint32_t)lddkv + head * DKP + oe) : ((uint32_t)(head * DKP + oe) * (uint32_t)MP + m0 + oq);
+    uint32_t doff = (m0 + oq) * (uint32_t)lddkv + head * DKP + oe;
     uint32_t rmoff = m0 + oq;
 
     // Pipeline.  The staged ring is three tiles deep: tile t+2 is fetched during tile t, so tile t+1 is already visible while tile t
@@ -225,22 +226,26 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
         }
         if (more) stage_store(nn);
         __syncthreads();
-        // ---- all 16 partials of tile qt are in LDS: fixed-order sum (as 8 packed pairs), scale, mask, store
+        // ---- all 16 partials of tile qt are in LDS: fixed-order sum (8 per lane as 4 packed pairs, then the two halves), scale, mask, store
         {
             asm volatile("" : "+v"(rm));                // first use of the mask value AFTER the barrier: no wait on its load before
             const float* pp = pbase + (qt & 1) * (MMT_FUSED_REGION_BYTES / 4);
             f32x2 v2 = {pp[0], pp[2 * MMT_FUSED_REGION_BYTES / 4]};
 #pragma unroll
-            for (int w2 = 2; w2 < MMT_FUSED_NW; w2 += 2) {
+            for (int w2 = 2; w2 < MMT_FUSED_NW / 2; w2 += 2) {
                 const f32x2 t = {pp[w2 * (2 * MMT_FUSED_REGION_BYTES / 4)], pp[(w2 + 1) * (2 * MMT_FUSED_REGION_BYTES / 4)]};
                 v2 += t;
             }
-            const float v = (v2[0] + v2[1]) * ((rm == 0.0f) ? 0.f : scale);     // blanked query rows pass no gradient to Q
-            bf16* const dbase = (opaque(lane) >> 5) ? dqkv : dqkvT;
-            if (orow) dbase[doff] = (bf16)v;
-            doff += (opaque(lane) >> 5) ? 32u * (uint32_t)lddkv : 32u;
-            rmoff += 32u;
+            const float half = v2[0] + v2[1];
+            // v_permlane32_swap a, b: lanes 32..63 of a <-> lanes 0..31 of b.  Written as asm: hipcc 7.2 folded the second result of
+            // __builtin_amdgcn_permlane32_swap into the first here (v_add v, v, v).  The s_nop covers the VALU-write -> permlane hazard.
+            float lo8 = half, hi8 = half;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo8), "+v"(hi8));      // every lane: lo8 = waves 0..7, hi8 = waves 8..15
+            const float v = (lo8 + hi8) * ((rm == 0.0f) ? 0.f : scale);     // blanked query rows pass no gradient to Q
+            if ((opaque(lane) >> 5) && orow) dqkv[doff] = (bf16)v;
         }
+        doff += 32u * (uint32_t)lddkv;
+        rmoff += 32u;
         const int t3 = cur; cur = nxt; nxt = nn; nn = t3;
     };
     for (int qt = 0; qt < nt - 1; ++qt) body(std::false_type{}, std::true_type{}, qt);
@@ -259,11 +264,6 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
             const int e0 = head * DKP + 8 * g + 4 * hh;
             *reinterpret_cast<bf16x4*>(dqkv + m * lddkv + HD + e0) = kv;
             *reinterpret_cast<bf16x4*>(dqkv + m * lddkv + 2 * HD + e0) = vv;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                dqkvT[(size_t)(HD + e0 + j) * MP + m] = kv[j];
-                dqkvT[(size_t)(2 * HD + e0 + j) * MP + m] = vv[j];
-            }
         }
     }
 }

@@ -2,7 +2,7 @@
 //   * encoder_prep_kernel  — fp32 master weights (flat, reference layout) -> zero-padded bf16 operand
 //                            copies (forward and transposed forms, head-padded where heads are < 16 wide)
 //   * layernorm_fwd/bwd    — the reference's LayerNorm alone (final norm of a stack; standalone module)
-//   * wgrad_kernel         — dW[n][k] = sum_m dY[m][n] X[m][k] from T-layout operands, split over windows
+//   * wgrad_kernel         — dW[n][k] = sum_m dY[m][n] X[m][k] from row-major operands (transposing LDS reads), split over windows
 //   * finalize kernels     — deterministic sums of the split slabs into the flat fp32 gradient
 #pragma once
 #include "common.h"
@@ -214,27 +214,42 @@ __global__ __launch_bounds__(MMT_THREADS) void layernorm_bwd_kernel(
 }
 
 // ---- weight gradients ---------------------------------------------------------------------------
-// dW[n][k] = sum_m At[n][m] * Bt[k][m]  (At = dY^T, Bt = X^T, both T layout [rows][MP], bf16).
-// One workgroup = one 64x64 output tile (4 waves as 2x2 of 32x32) over one slice of the windows;
-// slices go to separate fp32 slabs [nsplit][NP][KP] (+ [nsplit][NP] for the bias gradient = row sums
-// of At, taken from the A fragments on VALU), summed later by wgrad_finalize (deterministic).
+// dW[n][k] = sum_m A[m][n] * B[m][k]  with A = dY and B = X both ROW-MAJOR bf16 [MP rows][ld] (rows >= M are zero and never
+// written): the contraction runs over the windows m, the slow index of both operands.  Round 1 had every producer also write a
+// transposed ("T layout") copy of these eight operands so that an MFMA fragment was a plain 16-byte LDS read; those copies were
+// 45 % of the row kernels' HBM writes.  Now a [64 windows][64 features] tile of each operand is staged as it lies in memory
+// (full 128-byte lines) and the fragments come out of LDS already transposed by ds_read_b64_tr_b16 (gfx950's transposing read:
+// each 16-lane group gets a 4-window x 16-feature block column-major), two reads per 16-window k-step and operand.  LDS rows
+// are 192 bytes apart: the four rows a 32-lane half reads then fall into the four quarters of the 64 banks (conflict-free).
+// One workgroup = one 64x64 output tile (4 waves as 2x2 of 32x32) over one slice of the windows; slices go to separate fp32
+// slabs [nsplit][NP][KP] (+ [nsplit][NP] for the bias gradient = column sums of A, taken from the A fragments on VALU), summed
+// later by the finalize kernels (deterministic).
 struct WgradJob {
-    const bf16* At; const bf16* Bt; float* out; float* bias_out;
+    const bf16* A; const bf16* B; float* out; float* bias_out;
+    int lda, ldb;
     int NPj, KPj, tile0, tiles_k;
 };
 #define MMT_MAX_WGRAD_JOBS 64
 struct WgradJobs { WgradJob j[MMT_MAX_WGRAD_JOBS]; int njobs; int MP; int M16; int mchunk;
                    int tiles_per_layer, nlayers, nsplit; };    // > 0: 1-D XCD-aware grid (see wgrad_kernel); 0: grid = (tiles, splits)
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+// 8 contraction elements (windows 8hh .. 8hh+7 of a 16-window k-step) of this lane's feature, from a [window][feature] LDS tile
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* p, int row_stride) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * row_stride));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 __global__ __launch_bounds__(MMT_THREADS, 2) void wgrad_kernel(const WgradJobs jobs) {
-    // Operand tiles [64 features][64 windows] are fetched with full 128-byte lines (8 lanes x 16 B per feature row),
-    // the next chunk already in registers while the current one is multiplied out of LDS; rows are padded to 144 B so
-    // the 32-row x 16-byte fragment reads (ds_read_b128) are bank-conflict free.
-    constexpr int LDR = 72;                                    // bf16 elements per LDS row
+    constexpr int LDR = 96;                                    // bf16 elements per LDS row (192 bytes)
     __shared__ __attribute__((aligned(16))) bf16 As[2][64 * LDR];
     __shared__ __attribute__((aligned(16))) bf16 Bs[2][64 * LDR];
-    // Workgroup -> (tile, window split).  The tiles of one layer and one window split read the same eight T-layout operands (every
-    // operand row block is shared by 2..6 tiles).  Consecutive workgroup ids go round-robin to the 8 XCDs, each with a private
+    // Workgroup -> (tile, window split).  The tiles of one layer and one window split read the same eight operands (every
+    // operand column block is shared by 2..6 tiles).  Consecutive workgroup ids go round-robin to the 8 XCDs, each with a private
     // L2, so with a plain (tile, split) grid no two sharers met in an L2 and FETCH_SIZE was 2.7x the operand bytes.  The
     // encoder launch uses a 1-D grid in which ids congruent mod 8 — one XCD — carry whole (layer, split) units one after the
     // other.
@@ -254,19 +269,24 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void wgrad_kernel(const WgradJobs j
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int wn = wave >> 1, wk = wave & 1;
     const int mbeg = split * jobs.mchunk, mend = min(jobs.MP, mbeg + jobs.mchunk);
-    // staging role of this thread: rows row0 and row0+32 of each tile, 16-byte segment seg
+    // staging role of this thread: windows row0 and row0+32 of each 64-window chunk, 16-byte segment seg of the 64 features
     const int row0 = tid >> 3, seg = tid & 7;
-    const bf16* ag = J.At + (size_t)(tn * 64 + row0) * jobs.MP + seg * 8;
-    const bf16* bg = J.Bt + (size_t)(tk * 64 + row0) * jobs.MP + seg * 8;
-    const size_t half = (size_t)32 * jobs.MP;
+    const bf16* ag = J.A + (size_t)row0 * J.lda + tn * 64 + seg * 8;
+    const bf16* bg = J.B + (size_t)row0 * J.ldb + tk * 64 + seg * 8;
+    const size_t ahalf = (size_t)32 * J.lda, bhalf = (size_t)32 * J.ldb;
     const bool want_bias = (J.bias_out != nullptr) && tk == 0 && wk == 0;
+    // transposing-read role: 16-lane group g = lane >> 4 covers features 16(g&1) .. +15 of the wave's 32, windows 8(g>>1) .. +7 of a
+    // k-step; inside the group lane 4q + p addresses window q of a 4-window block, features 4p .. 4p+3
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int aoff = (8 * (g >> 1) + q) * LDR + wn * 32 + 16 * (g & 1) + 4 * pp;
+    const int boff = (8 * (g >> 1) + q) * LDR + wk * 32 + 16 * (g & 1) + 4 * pp;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float bsum = 0.f;
     if (mbeg < mend) {
-        bf16x8 ra0 = *reinterpret_cast<const bf16x8*>(ag + mbeg), ra1 = *reinterpret_cast<const bf16x8*>(ag + half + mbeg);
-        bf16x8 rb0 = *reinterpret_cast<const bf16x8*>(bg + mbeg), rb1 = *reinterpret_cast<const bf16x8*>(bg + half + mbeg);
+        bf16x8 ra0 = *reinterpret_cast<const bf16x8*>(ag + (size_t)mbeg * J.lda), ra1 = *reinterpret_cast<const bf16x8*>(ag + (size_t)mbeg * J.lda + ahalf);
+        bf16x8 rb0 = *reinterpret_cast<const bf16x8*>(bg + (size_t)mbeg * J.ldb), rb1 = *reinterpret_cast<const bf16x8*>(bg + (size_t)mbeg * J.ldb + bhalf);
         int buf = 0;
         for (int m = mbeg; m < mend; m += 64) {
             *reinterpret_cast<bf16x8*>(&As[buf][row0 * LDR + seg * 8]) = ra0;
@@ -275,15 +295,16 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void wgrad_kernel(const WgradJobs j
             *reinterpret_cast<bf16x8*>(&Bs[buf][(row0 + 32) * LDR + seg * 8]) = rb1;
             __syncthreads();
             if (m + 64 < mend) {                                // next chunk in flight behind this chunk's MFMAs
-                ra0 = *reinterpret_cast<const bf16x8*>(ag + m + 64); ra1 = *reinterpret_cast<const bf16x8*>(ag + half + m + 64);
-                rb0 = *reinterpret_cast<const bf16x8*>(bg + m + 64); rb1 = *reinterpret_cast<const bf16x8*>(bg + half + m + 64);
+                const size_t ao = (size_t)(m + 64) * J.lda, bo = (size_t)(m + 64) * J.ldb;
+                ra0 = *reinterpret_cast<const bf16x8*>(ag + ao); ra1 = *reinterpret_cast<const bf16x8*>(ag + ao + ahalf);
+                rb0 = *reinterpret_cast<const bf16x8*>(bg + bo); rb1 = *reinterpret_cast<const bf16x8*>(bg + bo + bhalf);
             }
-            const bf16* ap = &As[buf][(wn * 32 + r) * LDR + 8 * hh];
-            const bf16* bp = &Bs[buf][(wk * 32 + r) * LDR + 8 * hh];
+            const bf16* ap = &As[buf][aoff];
+            const bf16* bp = &Bs[buf][boff];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + ks * 16);
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp + ks * 16);
+                const bf16x8 a = tr_frag(ap + ks * 16 * LDR, LDR);
+                const bf16x8 b = tr_frag(bp + ks * 16 * LDR, LDR);
                 acc = mfma32(a, b, acc);
                 if (want_bias) {
 #pragma unroll

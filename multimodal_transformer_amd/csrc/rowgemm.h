@@ -4,14 +4,14 @@
 // products, their backward input-gradients, embeds, read-out MLPs) is an instance of this kernel.
 // One workgroup (4 waves) owns MMT_ROWS (16) consecutive windows — see "Tile height" below:
 //   1. A tile -> LDS as bf16 [32][KP+8] (optionally through the reference's LayerNorm, computed
-//      in fp32 from an fp32 LDS staging copy; optionally emitting the feature-major "T layout"
-//      copy that the weight-gradient kernel contracts over windows);
+//      in fp32 from an fp32 LDS staging copy; optionally emitting the tile as a row-major bf16
+//      array, an operand of the weight-gradient kernel);
 //   2. per 128-column chunk, wave w multiplies the tile by W rows [n0+32w, n0+32w+32) with
 //      mfma_f32_16x16x32_bf16 (W fragments straight from L2: each is used by exactly one wave,
 //      two k-blocks in flight), and parks its fp32 accumulators in an LDS tile;
 //   3. a row-wise epilogue reads that LDS tile with a thread->(row, 4 columns) mapping, so all
 //      global traffic is 8/16-byte coalesced whatever the MFMA accumulator layout was.
-// Epilogues: PLAIN (bias/ReLU/ReLU-mask/residual/row-scale; fp32, bf16 and T-layout outputs),
+// Epilogues: PLAIN (bias/ReLU/ReLU-mask/residual/row-scale; fp32 and bf16 outputs),
 //            FRAG  (attention operand fragment layouts for Q/K/V or dO, plus delta = rowsum(dO.O)),
 //            LNBWD (LayerNorm backward fused behind the input-gradient GEMM + residual gradient).
 #pragma once
@@ -64,7 +64,7 @@ struct RowGemmParams {
     int M, K, KP, N, NP;
     // ---- A operand ----
     const void* A; int a_bf16; int lda;
-    bf16* At_out; int ldt;                 // optional T-layout copy of the bf16 A tile: [KP][ldt]
+    bf16* A_out; int lda_out;              // optional row-major copy of the bf16 A tile [M][lda_out] (an operand of the weight-gradient kernel)
     DropCfg a_drop;                        // thr16 != 0: fp32 A is multiplied by the dropout mask of index m*KP + k on load
     // LayerNorm prologue (A must be fp32, K = feature count)
     const float* ln_a; const float* ln_b; float eps; float* stats;   // stats: [M][2] = (mean, 1/(std+eps))
@@ -78,7 +78,6 @@ struct RowGemmParams {
     const float* rowscale;                 // multiply row m by rowscale[m]
     float* out_f32; int ldo;
     bf16* out_bf16; int ldo16; int n_store16;   // columns [0, n_store16) are written (pads come out as exact zeros)
-    bf16* out_T; int ldoT;                 // [NP][ldoT]
     // ---- FRAG ----
     bf16* fragR[3]; bf16* fragT[3];
     int T, Tp, h, DKP, nwhich;             // N covers nwhich * h * DKP columns
@@ -241,22 +240,15 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     __syncthreads();
     PHASE(0);                                                 // A tile staged (LayerNorm prologue included)
 
-    if (p.At_out) {   // T-layout copy of the bf16 tile: task = (feature k, group of 8 rows)
-        // row group fastest: the 4 lanes of one feature write its 32 windows = 64 contiguous bytes (feature fastest made every
-        // lane's 16 bytes a separate write transaction)
-        for (int task = tid; task < KP * MMT_RG8; task += MMT_RTHREADS) {
-            const int rg = task % MMT_RG8, k = task / MMT_RG8, mb = m0 + rg * 8;
-            if (mb >= M) continue;
-            bf16x8 v;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = As[(rg * 8 + i) * lda_s + k];
-            bf16* dst = p.At_out + (size_t)k * p.ldt + mb;
-            if (mb + 8 <= M) *reinterpret_cast<bf16x8*>(dst) = v;
-            else for (int i = 0; i < 8 && mb + i < M; ++i) dst[i] = v[i];
+    if (p.A_out) {    // row-major copy of the bf16 tile (16-byte pieces, whole rows contiguous)
+        const int k8 = KP >> 3;
+        for (int idx = tid; idx < ROWS * k8; idx += MMT_RTHREADS) {
+            const int row = idx / k8, c = (idx - row * k8) * 8, m = m0 + row;
+            if (m < M) *reinterpret_cast<bf16x8*>(p.A_out + (size_t)m * p.lda_out + c) = *reinterpret_cast<const bf16x8*>(As + row * lda_s + c);
         }
     }
 
-    PHASE(1);                                                 // T-layout copy of the A tile
+    PHASE(1);                                                 // row-major copy of the A tile
     // ------------------------------------------------------------------ 2. chunks of 128 columns
     for (int n0 = 0; n0 < NP; n0 += 128) {
         const int nb = n0 + wave * MMT_WCOLS;
@@ -398,29 +390,12 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                         else for (int i = 0; i < 4 && n + i < p.n_store16; ++i) dst[i] = o[i];
                     }
                 }
-                if (p.out_T) *reinterpret_cast<f32x4*>(Fs + row * ldf + cg * 4) = v[it];   // final values for the T pass
                 if (KEEP & KEEP_X) *reinterpret_cast<f32x4*>(Xs + row * sm.ldx + n) = v[it];
                 if (KEEP & KEEP_A2) {
                     bf16x4 o;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[i] = (bf16)v[it][i];
                     *reinterpret_cast<bf16x4*>(sm.A2 + row * sm.lda2 + n) = o;
-                }
-            }
-            if (p.out_T) {
-                __syncthreads();
-#pragma unroll
-                for (int it = 0; it < (128 * MMT_RG8 + MMT_RTHREADS - 1) / MMT_RTHREADS; ++it) {      // 128 columns x MMT_RG8 row groups
-                    const int task = tid + it * MMT_RTHREADS;
-                    const int rg = task % MMT_RG8, c = task / MMT_RG8, n = n0 + c, mb = m0 + rg * 8;       // row group fastest: 16 B x MMT_RG8 runs
-                    if (c >= 128) continue;
-                    if (n >= NP || mb >= M) continue;
-                    bf16x8 v;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = (bf16)Fs[(rg * 8 + i) * ldf + c];
-                    bf16* dst = p.out_T + (size_t)n * p.ldoT + mb;
-                    if (mb + 8 <= M) *reinterpret_cast<bf16x8*>(dst) = v;
-                    else for (int i = 0; i < 8 && mb + i < M; ++i) dst[i] = v[i];
                 }
             }
         } else if (EPI == EPI_FRAG) {
