@@ -345,6 +345,17 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
         ProfScope prof(S_ATTN_BWD_FUSED, st);
 #define MMT_FUSED(dr) hipLaunchKernelGGL((attn_bwd_fused16_kernel<dr>), dim3(D.B * D.h), dim3(MMT_FUSED_THREADS), MMT_FUSED_LDS_BYTES, st, \
                                           QR, QT, KR, KT_, VR, dOR, dOT, lse, delta, rowmask, scale, dqkv, D.L.NQ, D.h, D.T, D.nt, maskK, drop.scale)
+#ifdef MMT_ABLATIONS
+        static const bool stamp = getenv("MMT_ABL") && atoi(getenv("MMT_ABL")) == 7;
+        if (stamp && drop.thr16) {
+            static bool c2 = false;
+            if (!c2) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); c2 = true; }
+            hipLaunchKernelGGL((attn_bwd_fused16_kernel<true, true>), dim3(D.B * D.h), dim3(MMT_FUSED_THREADS), MMT_FUSED_LDS_BYTES, st,
+                               QR, QT, KR, KT_, VR, dOR, dOT, lse, delta, rowmask, scale, dqkv, D.L.NQ, D.h, D.T, D.nt, maskK, drop.scale);
+            LAUNCH_CHECK("attn_bwd_fused16_kernel");
+            return MMT_OK;
+        }
+#endif
         if (drop.thr16) MMT_FUSED(true); else MMT_FUSED(false);
 #undef MMT_FUSED
         LAUNCH_CHECK("attn_bwd_fused16_kernel");

@@ -31,7 +31,15 @@
 
 __host__ inline bool attn_bwd_fused_ok(int DKP, int nt) { return DKP == 16 && nt > 8 && nt <= MMT_FUSED_NW; }
 
-template <bool DROP>
+// STAMP (diagnostic build, -DMMT_ABLATIONS): s_memtime at six points of the tile body, summed per wave into g_attn_stamps
+#ifdef MMT_ABLATIONS
+#define FB_STAMP(n) do { if (STAMP) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    st_acc[n] += t_ - st_prev; st_prev = t_; } } while (0)
+#else
+#define FB_STAMP(n)
+#endif
+template <bool DROP, bool STAMP = false>
 __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
         const bf16* __restrict__ Qr, const bf16* __restrict__ Qt, const bf16* __restrict__ Kr, const bf16* __restrict__ Kt,
         const bf16* __restrict__ Vr, const bf16* __restrict__ dOr, const bf16* __restrict__ dOt,
@@ -150,7 +158,33 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
         for (int j = 0; j < 16; ++j) { s[j] = 0.f; dp[j] = 0.f; }
     }
     int cur = 0, nxt = 1, nn = 2;       // ring slots of tiles qt, qt+1, qt+2
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_entry = 0;
+    (void)st_acc; (void)st_prev; (void)st_entry;
+#ifdef MMT_ABLATIONS
+    if (STAMP) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory"); st_entry = st_prev; }
+#endif
 
+    // dQ reduction of one tile (all 16 partials are in LDS once the tile's barrier has been passed): fixed-order sum (8 per lane as 4
+    // packed pairs, then the two half-waves), scale, query-row mask, store.  (Running it one tile late, in the slack in front of the
+    // next tile's barrier, was measured: 47.4 -> 49.2 us per launch; it stays directly behind its own barrier.)
+    auto reduce_dq = [&](int qt, float rm, bool orow) {
+        asm volatile("" : "+v"(rm));                    // first use of the mask value long after its load
+        const float* pp = pbase + (qt & 1) * (MMT_FUSED_REGION_BYTES / 4);
+        f32x2 v2 = {pp[0], pp[2 * MMT_FUSED_REGION_BYTES / 4]};
+#pragma unroll
+        for (int w2 = 2; w2 < MMT_FUSED_NW / 2; w2 += 2) {
+            const f32x2 t = {pp[w2 * (2 * MMT_FUSED_REGION_BYTES / 4)], pp[(w2 + 1) * (2 * MMT_FUSED_REGION_BYTES / 4)]};
+            v2 += t;
+        }
+        const float half = v2[0] + v2[1];
+        // v_permlane32_swap a, b: lanes 32..63 of a <-> lanes 0..31 of b.  Written as asm: hipcc 7.2 folded the second result of
+        // __builtin_amdgcn_permlane32_swap into the first here (v_add v, v, v).  The s_nop covers the VALU-write -> permlane hazard.
+        float lo8 = half, hi8 = half;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo8), "+v"(hi8));      // every lane: lo8 = waves 0..7, hi8 = waves 8..15
+        const float v = (lo8 + hi8) * ((rm == 0.0f) ? 0.f : scale);     // blanked query rows pass no gradient to Q
+        if ((opaque(lane) >> 5) && orow) dqkv[doff] = (bf16)v;
+        doff += 32u * (uint32_t)lddkv;
+    };
     auto body = [&](auto tail_tag, auto next_tag, int qt) {
         constexpr bool QTAIL = decltype(tail_tag)::value;
         constexpr bool NEXT = decltype(next_tag)::value;                        // a tile qt+1 exists
@@ -160,6 +194,7 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
         const bool orow = !QTAIL || (qt * 32 + oq) < T;
         float rm = rowmask ? rowmask[orow ? rmoff : m0] : 1.f;
         char* const region = myreg + (qt & 1) * MMT_FUSED_REGION_BYTES;
+        FB_STAMP(0);                                    // loop top: prefetch issue
         if (live) {
             const uint32_t tw = mw;
             if (DROP && NEXT) mw = mrow[(size_t)(qt + 1) * 64];
@@ -193,6 +228,7 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
 #pragma unroll
                 for (int j = 0; j < 16; ++j) dp[j] *= s[j];
             }
+            FB_STAMP(1);                                // exponentials, dropout, dS
             // dV^T / dK^T, and dS into the patch on the way.  This lane's key column goes where the K^T tile's k-order wants it (bits 2
             // and 3 of the key swapped).
             const int lo = opaque(lane), r = lo & 31, hh = lo >> 5, rq = r ^ 16;
@@ -208,6 +244,7 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
                 for (int j = 0; j < 8; ++j)             // register 8*s2 + j holds query row acc32_row(8*s2 + j, hh) of this lane's key
                     patch[acc32_row(8 * s2 + j, hh) * MMT_FUSED_PATCH_LD + pcol] = pds[j];
             }
+            FB_STAMP(2);                                // packs, dV/dK products, patch writes
             // dQ^T share of this key tile: K^T (features x keys) times dS^T (keys x queries); lanes r >= 16 would produce the padding
             // feature rows, which nobody reads, so they fetch the same K^T rows as lanes r - 16
             f32x16 dqp;
@@ -222,34 +259,29 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
             float* const part = reinterpret_cast<float*>(region);
 #pragma unroll
             for (int j = 0; j < 8; ++j) part[j * MMT_FUSED_PART_LD + lo] = dqp[j];          // feature rows >= 16 are padding
+            FB_STAMP(3);                                // patch reads, dQ product, partial writes
             if (NEXT) scores(nxt);                      // tile qt+1 has been visible since the previous barrier
+            FB_STAMP(4);                                // next tile's row constants, operand reads and score products
         }
         if (more) stage_store(nn);
         __syncthreads();
-        // ---- all 16 partials of tile qt are in LDS: fixed-order sum (8 per lane as 4 packed pairs, then the two halves), scale, mask, store
-        {
-            asm volatile("" : "+v"(rm));                // first use of the mask value AFTER the barrier: no wait on its load before
-            const float* pp = pbase + (qt & 1) * (MMT_FUSED_REGION_BYTES / 4);
-            f32x2 v2 = {pp[0], pp[2 * MMT_FUSED_REGION_BYTES / 4]};
-#pragma unroll
-            for (int w2 = 2; w2 < MMT_FUSED_NW / 2; w2 += 2) {
-                const f32x2 t = {pp[w2 * (2 * MMT_FUSED_REGION_BYTES / 4)], pp[(w2 + 1) * (2 * MMT_FUSED_REGION_BYTES / 4)]};
-                v2 += t;
-            }
-            const float half = v2[0] + v2[1];
-            // v_permlane32_swap a, b: lanes 32..63 of a <-> lanes 0..31 of b.  Written as asm: hipcc 7.2 folded the second result of
-            // __builtin_amdgcn_permlane32_swap into the first here (v_add v, v, v).  The s_nop covers the VALU-write -> permlane hazard.
-            float lo8 = half, hi8 = half;
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo8), "+v"(hi8));      // every lane: lo8 = waves 0..7, hi8 = waves 8..15
-            const float v = (lo8 + hi8) * ((rm == 0.0f) ? 0.f : scale);     // blanked query rows pass no gradient to Q
-            if ((opaque(lane) >> 5) && orow) dqkv[doff] = (bf16)v;
-        }
-        doff += 32u * (uint32_t)lddkv;
+        FB_STAMP(5);                                    // staging store + barrier
+        reduce_dq(qt, rm, orow);
+        FB_STAMP(6);                                    // dQ reduction and store
         rmoff += 32u;
         const int t3 = cur; cur = nxt; nxt = nn; nn = t3;
     };
     for (int qt = 0; qt < nt - 1; ++qt) body(std::false_type{}, std::true_type{}, qt);
     if (T & 31) body(std::true_type{}, std::false_type{}, nt - 1); else body(std::false_type{}, std::false_type{}, nt - 1);
+#ifdef MMT_ABLATIONS
+    if (STAMP && g_attn_stamps && lane == 0) {
+        unsigned long long t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+        unsigned long long* q = g_attn_stamps + ((size_t)blockIdx.x * MMT_FUSED_NW + wave) * 16;
+        for (int i = 0; i < 7; ++i) q[i] = st_acc[i];
+        q[7] = t1 - st_entry; q[9] = live ? 1 : 2;
+    }
+#endif
     if (!live) return;
     // dK = ln2 * acc rows 16.. (scores are in the log2 domain), dV = acc rows 0..15; column key = r
     const float LN2 = 0.6931471805599453f;

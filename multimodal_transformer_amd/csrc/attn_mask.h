@@ -35,7 +35,8 @@ __device__ __forceinline__ void attn_keep_block(const DropCfg& dc, uint32_t blk,
     uint32_t x = drop_lin(dc.s0, blk * 512u) + (uint32_t)b0 * MMT_DROP_C1;   // word index blk*512 + key*16 + b  (< 2^24 for Tp <= 4096)
 #pragma unroll
     for (int key = 0; key < 32; ++key) W[key] = 0;                // the drop words D; threshold bits below b0 leave them 0
-    // threshold bit outermost (a uniform, rolled loop), the 32 keys unrolled inside: 32 independent hash chains in flight
+    // threshold bit outermost (a uniform, rolled loop), the 32 keys unrolled inside: 32 independent hash chains in flight (124 VGPRs,
+    // 4 waves per SIMD; 16 chains at 6 or 8 waves per SIMD measured no faster: the kernel is bound by integer issue, not latency)
 #pragma unroll 1
     for (int b = b0; b < 16; ++b) {
         if ((thr >> b) & 1u) {

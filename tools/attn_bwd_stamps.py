@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Developer tool: where does attn_bwd_fused16_kernel<train> spend its tile time?  Needs tools/bin/libmmt_abl.so (built with
+-DMMT_ABLATIONS); runs the configs[3] encoder forward+backward with the stamped variant of the kernel (MMT_ABL=7)."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["MMT_ABL"] = "7"
+os.environ["MMT_LIB_PATH"] = os.path.join(ROOT, "tools", "bin", "libmmt_abl.so")
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from multimodal_transformer_amd import multiTransformer as MT, _lib
+
+SEG = ["loop top (prefetch issue)", "exp + dropout + dS", "packs + dV/dK MFMAs + patch writes", "patch reads + dQ MFMA + partial writes",
+       "next tile: row constants, operand reads, score MFMAs", "staging store + barrier", "dQ reduction + store"]
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+B, T, d, h = 32, 500, 128, 8
+enc = MT.Encoder(MT.EncoderLayer(d, MT.MultiHeadedAttention(h, d), MT.PositionwiseFeedForward(d, 128, 0.1), 0.1), 6).to(dev).train()
+x = torch.randn(B, T, d, device=dev, requires_grad=True)
+mask = torch.ones(B, T, 1, device=dev)
+raw = ctypes.CDLL(_lib.LIB_PATH)
+raw.mmt_debug_set_attn_stamp_buffer.argtypes = [ctypes.c_void_p]
+stamps = torch.zeros(B * h * 16 * 16, dtype=torch.int64, device=dev)
+for _ in range(5):
+    enc(x, mask).sum().backward()
+torch.cuda.synchronize()
+assert raw.mmt_debug_set_attn_stamp_buffer(ctypes.c_void_p(stamps.data_ptr())) == 0
+_lib.profile(True)
+for _ in range(5):
+    enc(x, mask).sum().backward()
+torch.cuda.synchronize()
+ms, n = _lib.profile_collect()["attn_bwd_fused16_kernel"]
+print("attn_bwd_fused16 (stamped) %.2f us/launch" % (1e3 * ms / n))
+full = stamps.cpu().numpy().reshape(-1, 16).astype(float)
+live = full[full[:, 9] == 1]
+life = live[:, 7]
+print("live waves %d: lifetime median %.0f cycles (min %.0f max %.0f) = %.0f per tile" % (len(live), np.median(life), life.min(), life.max(), np.median(life) / 16))
+tot = live[:, :7].sum()
+for i, nm in enumerate(SEG):
+    print("  %-56s %6.0f cycles/tile  %5.1f %%" % (nm, live[:, i].mean() / 16, 100 * live[:, i].sum() / tot))
