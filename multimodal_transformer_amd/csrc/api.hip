@@ -111,7 +111,7 @@ static int make_dims(EncDims& D, int B, int T, int d, int h, int f, int N) {
     if (N > MAX_LAYERS) return fail(MMT_EUNSUPPORTED, "n_layers %d > %d", N, MAX_LAYERS);
     if (d % h) return fail(MMT_EINVAL, "d_model %d not divisible by h %d", d, h);   // multiTransformer.py:39
     if (d % 4 || f % 4) return fail(MMT_EUNSUPPORTED, "d_model and d_ff must be multiples of 4 (got %d, %d)", d, f);
-    if (d / h > 32) return fail(MMT_EUNSUPPORTED, "d_k = %d > 32 not supported", d / h);
+    if (d / h > 64) return fail(MMT_EUNSUPPORTED, "d_k = %d > 64 not supported", d / h);
     if (d < 2) return fail(MMT_EINVAL, "d_model < 2 (unbiased std undefined)");
     D.B = B; D.T = T; D.d = d; D.h = h; D.f = f; D.N = N;
     D.M = B * T; D.MP = round_up(D.M, 64); D.M16 = round_up(D.M, 16);
@@ -170,8 +170,8 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
         w.xn1 = c.take<bf16>(MP * L.DP); w.xn2 = c.take<bf16>(MP * L.DP);          // MP rows: rows >= M stay zero for wgrad
         w.QR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); w.KR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP));
         w.VR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP));
-        w.QT = c.take<bf16>(BH * fragT_elems(D.Tp)); w.KT = c.take<bf16>(BH * fragT_elems(D.Tp));
-        w.VT = c.take<bf16>(BH * fragT_elems(D.Tp));
+        w.QT = c.take<bf16>(BH * fragT_elems(D.Tp, L.DKP)); w.KT = c.take<bf16>(BH * fragT_elems(D.Tp, L.DKP));
+        w.VT = c.take<bf16>(BH * fragT_elems(D.Tp, L.DKP));
         w.ctx = c.take<bf16>(MP * L.HDP); w.hid = c.take<bf16>(MP * L.FP);
         w.dx2 = c.take<bf16>(MP * L.DP); w.dh = c.take<bf16>(MP * L.FP);
         w.dx1 = c.take<bf16>(MP * L.DP); w.dqkv = c.take<bf16>(MP * L.NQ);
@@ -188,7 +188,7 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
     W.dxa = c.take<float>(M * D.d); W.dxb = c.take<float>(M * D.d);
     W.delta = c.take<float>(BH * D.Tp);
     W.lnpartf = c.take<float>((size_t)D.G * 2 * L.DP);
-    W.dOR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); W.dOT = c.take<bf16>(BH * fragT_elems(D.Tp));
+    W.dOR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); W.dOT = c.take<bf16>(BH * fragT_elems(D.Tp, L.DKP));
     const size_t S = D.nsplit;
     {   // one slab set per layer, identical sizes: layer l's set lives at + l * slab_stride floats
         const size_t before = c.off;
@@ -302,17 +302,19 @@ static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* 
     if (!big) {
         int rc2;
         if ((rc2 = allow_big_lds(&attn_fwd_kernel<16, true>, 6144)) || (rc2 = allow_big_lds(&attn_fwd_kernel<16, false>, 6144)) ||
-            (rc2 = allow_big_lds(&attn_fwd_kernel<32, true>, 8192)) || (rc2 = allow_big_lds(&attn_fwd_kernel<32, false>, 8192))) return rc2;
+            (rc2 = allow_big_lds(&attn_fwd_kernel<32, true>, 8192)) || (rc2 = allow_big_lds(&attn_fwd_kernel<32, false>, 8192)) ||
+            (rc2 = allow_big_lds(&attn_fwd_kernel<64, true>, 12288)) || (rc2 = allow_big_lds(&attn_fwd_kernel<64, false>, 12288))) return rc2;
         big = true;
     }
-    const size_t bal = balance_lds((int)grid.x, (size_t)2 * (DKP * 4 + 128) * 16);
+    const size_t bal = balance_lds((int)grid.x, (size_t)2 * (DKP * 4 + 128) * 16);      // the kernel's static LDS: two staging slots
     ProfScope prof(S_ATTN_FWD, st);
-#define MMT_FWD(dkp, dr) hipLaunchKernelGGL((attn_fwd_kernel<dkp, dr>), grid, dim3(MMT_THREADS), bal, st, QR, KR, VT, ctx, lse, \
-                                            D.h, D.T, D.nt, D.B * D.h, D.L.HDP, maskQ, drop.scale)
+#define MMT_FWD(dkp, dr) for (int fb = 0; fb < (dkp + 31) / 32; ++fb) \
+        hipLaunchKernelGGL((attn_fwd_kernel<dkp, dr>), grid, dim3(MMT_THREADS), bal, st, QR, KR, VT, ctx, lse, \
+                           D.h, D.T, D.nt, D.B * D.h, D.L.HDP, maskQ, drop.scale, fb)
 #ifdef MMT_ABLATIONS
     static const int abl = getenv("MMT_ABL") ? atoi(getenv("MMT_ABL")) : 0;
 #define MMT_FWD_A(a) hipLaunchKernelGGL((attn_fwd_kernel<16, true, a>), grid, dim3(MMT_THREADS), (a == 6 ? (allow_big_lds(&attn_fwd_kernel<16, true, 6>, 6144), bal) : 0), st, QR, KR, VT, ctx, lse, \
-                                        D.h, D.T, D.nt, D.B * D.h, D.L.HDP, maskQ, drop.scale)
+                                        D.h, D.T, D.nt, D.B * D.h, D.L.HDP, maskQ, drop.scale, 0)
     if (abl && DKP == 16 && drop.thr16) {
         switch (abl) { case 1: MMT_FWD_A(1); break; case 2: MMT_FWD_A(2); break; case 3: MMT_FWD_A(3); break; case 4: MMT_FWD_A(4); break;
                        case 5: MMT_FWD_A(5); break; default: MMT_FWD_A(6); }
@@ -320,7 +322,8 @@ static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* 
     }
 #endif
     if (DKP == 16) { if (drop.thr16) MMT_FWD(16, true); else MMT_FWD(16, false); }
-    else { if (drop.thr16) MMT_FWD(32, true); else MMT_FWD(32, false); }
+    else if (DKP == 32) { if (drop.thr16) MMT_FWD(32, true); else MMT_FWD(32, false); }
+    else { if (drop.thr16) MMT_FWD(64, true); else MMT_FWD(64, false); }
 #undef MMT_FWD
     LAUNCH_CHECK("attn_fwd_kernel");
     return MMT_OK;
@@ -363,19 +366,23 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
     }
     {
         ProfScope prof(S_ATTN_BWD, st);
-#define MMT_DKV(dkp, dr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, QT, KR, VR, dOR, dOT, lse, delta, \
-                                            dqkv, D.L.NQ, D.h, D.T, D.nt, D.B * D.h, maskK, drop.scale)
+#define MMT_DKV(dkp, dr) for (int fb = 0; fb < (dkp + 31) / 32; ++fb) \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, QT, KR, VR, dOR, dOT, lse, delta, \
+                           dqkv, D.L.NQ, D.h, D.T, D.nt, D.B * D.h, maskK, drop.scale, fb)
         if (DKP == 16) { if (drop.thr16) MMT_DKV(16, true); else MMT_DKV(16, false); }
-        else { if (drop.thr16) MMT_DKV(32, true); else MMT_DKV(32, false); }
+        else if (DKP == 32) { if (drop.thr16) MMT_DKV(32, true); else MMT_DKV(32, false); }
+        else { if (drop.thr16) MMT_DKV(64, true); else MMT_DKV(64, false); }
 #undef MMT_DKV
     }
     LAUNCH_CHECK("attn_bwd_dkv_kernel");
     {
         ProfScope prof(S_ATTN_BWD_DQ, st);
-#define MMT_DQ(dkp, dr) hipLaunchKernelGGL((attn_bwd_dq_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, KT_, VR, dOR, lse, delta, rowmask, \
-                                           scale, dqkv, D.L.NQ, D.h, D.T, D.nt, D.B * D.h, maskQ, drop.scale)
+#define MMT_DQ(dkp, dr) for (int fb = 0; fb < (dkp + 31) / 32; ++fb) \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, KT_, VR, dOR, lse, delta, rowmask, \
+                           scale, dqkv, D.L.NQ, D.h, D.T, D.nt, D.B * D.h, maskQ, drop.scale, fb)
         if (DKP == 16) { if (drop.thr16) MMT_DQ(16, true); else MMT_DQ(16, false); }
-        else { if (drop.thr16) MMT_DQ(32, true); else MMT_DQ(32, false); }
+        else if (DKP == 32) { if (drop.thr16) MMT_DQ(32, true); else MMT_DQ(32, false); }
+        else { if (drop.thr16) MMT_DQ(64, true); else MMT_DQ(64, false); }
 #undef MMT_DQ
     }
     LAUNCH_CHECK("attn_bwd_dq_kernel");
@@ -681,7 +688,7 @@ __global__ void pack_frag_kernel(const float* __restrict__ src, bf16* __restrict
         for (int e = 0; e < dk; ++e) {
             const bf16 v = (bf16)(src[(size_t)m * d + head * dk + e] * sc);
             fr[bh * fragR_elems(Tp, DKP) + fragR_index(t, e, DKP)] = v;
-            ft[bh * fragT_elems(Tp) + fragT_index(t, e)] = v;
+            ft[bh * fragT_elems(Tp, DKP) + fragT_index(t, e, Tp)] = v;
             if (delta) part += (float)v * (float)ctx[(size_t)m * ldctx + head * DKP + e];
         }
         if (delta) delta[bh * Tp + t] = -part;       // stored negated, like the fused path
@@ -704,7 +711,7 @@ static void carve_sdpa(SdpaWs& W, const EncDims& D, void* base) {
     const size_t BH = (size_t)D.B * D.h, M = D.M;
     bf16** r[] = {&W.QR, &W.KR, &W.VR, &W.dOR};
     bf16** t[] = {&W.QT, &W.KT, &W.VT, &W.dOT};
-    for (int i = 0; i < 4; ++i) { *r[i] = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); *t[i] = c.take<bf16>(BH * fragT_elems(D.Tp)); }
+    for (int i = 0; i < 4; ++i) { *r[i] = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); *t[i] = c.take<bf16>(BH * fragT_elems(D.Tp, L.DKP)); }
     W.ctx = c.take<bf16>(M * L.HDP);
     W.dqkv = c.take<bf16>(M * L.NQ);
     W.lse = c.take<float>(BH * D.Tp); W.delta = c.take<float>(BH * D.Tp);

@@ -16,6 +16,9 @@
 #include "attn_mask.h"
 
 // ------------------------------------------------------------------------------------------------
+// d_k = 64 (DKP = 64): the score products contract over all 64 features (KS = 4 k-steps), but a 32x32 MFMA accumulator holds only 32
+// feature rows of an output (O^T, dK^T, dV^T, dQ^T): each launch produces ONE 32-feature block `fb` of its outputs and the host
+// launches twice — the scores are evaluated twice, which this rarely used head size (no BASELINE config has d_k > 32) can afford.
 // All three kernels below: a 1-D grid decoded by attn_block() into (tile quad, batch*head), 4 waves per workgroup, each wave owning one 32-window
 // tile of its own and sweeping the other axis.  The swept operand tile (K/V for the forward and dQ kernels,
 // Q/dO/L/delta for the dK-dV kernel) is the same for the four waves, so the workgroup stages it into LDS
@@ -119,8 +122,9 @@ template <int DKP, bool DROP, int ABL = 0>
 __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
         const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vt,
         bf16* __restrict__ ctx, float* __restrict__ lse,
-        int h, int T, int nt, int nbh, int ldc, const uint16_t* __restrict__ maskQ, float drop_scale) {
+        int h, int T, int nt, int nbh, int ldc, const uint16_t* __restrict__ maskQ, float drop_scale, int fb) {
     constexpr int KS = DKP / 16;
+    constexpr int DKB = DKP < 32 ? DKP : 32;           // feature rows of this launch's output block
     constexpr bool ONES = (DKP == 16) && !DROP;        // row sums through the MFMA
 #ifdef MMT_ABLATIONS
     unsigned long long st_entry = 0, st_entry_rt = 0;
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
     const int Tp = nt * 32;
     const bf16* Qb = Qr + (size_t)bh * fragR_elems(Tp, DKP);
     const bf16* Kb = Kr + (size_t)bh * fragR_elems(Tp, DKP);
-    const bf16* Vb = Vt + (size_t)bh * fragT_elems(Tp);
+    const bf16* Vb = Vt + (size_t)bh * fragT_elems(Tp, DKP) + (size_t)fb * Tp * 32;
     // dropout: this lane's 16-bit words of the wave's row of mask blocks (attn_mask.h, LQ layout), one per key tile, fetched a tile ahead
     const uint16_t* mrow = maskQ + ((size_t)bh * nt + qtc) * nt * 64 + lane;
     uint32_t mw = DROP ? mrow[0] : 0u;
@@ -260,11 +264,11 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
         if (hh == 0) lse[(size_t)bh * Tp + t] = -(mrun + fast_log2(ltot));   // stored NEGATED: it is the accumulator init of the backward
         // O^T rows (head features) live in registers: e = acc32_row(i, hh); groups of 4 are contiguous
 #pragma unroll
-        for (int g = 0; g < DKP / 8; ++g) {
+        for (int g = 0; g < DKB / 8; ++g) {
             bf16x4 v;
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = (bf16)(o[4 * g + i] * inv);
-            const int e0 = 8 * g + 4 * hh;
+            const int e0 = 32 * fb + 8 * g + 4 * hh;
             *reinterpret_cast<bf16x4*>(ctx + m * ldc + head * DKP + e0) = v;
         }
     }
@@ -295,8 +299,9 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
         const bf16* __restrict__ dOr, const bf16* __restrict__ dOt,
         const float* __restrict__ lse, const float* __restrict__ delta,
         bf16* __restrict__ dkv, int lddkv,      // row-major [M][lddkv]; dK at column HD, dV at 2*HD
-        int h, int T, int nt, int nbh, const uint16_t* __restrict__ maskK, float drop_scale) {
+        int h, int T, int nt, int nbh, const uint16_t* __restrict__ maskK, float drop_scale, int fb) {
     constexpr int KS = DKP / 16;
+    constexpr int DKB = DKP < 32 ? DKP : 32;
     constexpr int PR = DKP * 4, PT = 128, PC = 8;       // pieces: R-layout tile, T-layout tile, 32 fp32 row constants
     constexpr int TOTAL = 2 * PR + 2 * PT + 2 * PC;
     __shared__ __attribute__((aligned(16))) bf16 stage[2][TOTAL * 8];
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
     const int ktc = live ? kt : nt - 1;
     const int bh = ab.bh, b = bh / h, head = bh - b * h;
     const int Tp = nt * 32, HD = h * DKP;
-    const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
+    const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp, DKP) + (size_t)fb * Tp * 32;
     const bf16 *Krb = Kr + offR, *Vrb = Vr + offR;
     const uint16_t* mrow = maskK + ((size_t)bh * nt + ktc) * nt * 64 + lane;      // LK layout: this lane's word of one block per query tile
     uint32_t mw = DROP ? mrow[0] : 0u;
@@ -421,14 +426,14 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
     if (t < T) {
         const size_t m = (size_t)b * T + t;
 #pragma unroll
-        for (int g = 0; g < DKP / 8; ++g) {
+        for (int g = 0; g < DKB / 8; ++g) {
             bf16x4 kv, vv;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 kv[j] = (bf16)((ONEACC ? dVacc[8 + 4 * g + j] : dKacc[4 * g + j]) * LN2);      // ONEACC: rows 16 + e sit in registers 8..15
                 vv[j] = (bf16)dVacc[4 * g + j];
             }
-            const int e0 = head * DKP + 8 * g + 4 * hh;
+            const int e0 = head * DKP + 32 * fb + 8 * g + 4 * hh;
             *reinterpret_cast<bf16x4*>(dkv + m * lddkv + HD + e0) = kv;
             *reinterpret_cast<bf16x4*>(dkv + m * lddkv + 2 * HD + e0) = vv;
         }
@@ -446,8 +451,9 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
         const bf16* __restrict__ dOr, const float* __restrict__ lse, const float* __restrict__ delta,
         const float* __restrict__ rowmask, float scale,
         bf16* __restrict__ dqkv, int lddqkv,
-        int h, int T, int nt, int nbh, const uint16_t* __restrict__ maskQ, float drop_scale) {
+        int h, int T, int nt, int nbh, const uint16_t* __restrict__ maskQ, float drop_scale, int fb) {
     constexpr int KS = DKP / 16;
+    constexpr int DKB = DKP < 32 ? DKP : 32;
     constexpr int PR = DKP * 4, PT = 128;
     __shared__ __attribute__((aligned(16))) bf16 stage[2][(2 * PR + PT) * 8];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
     const int qtc = live ? qt : nt - 1;
     const int bh = ab.bh, b = bh / h, head = bh - b * h;
     const int Tp = nt * 32;
-    const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
+    const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp, DKP) + (size_t)fb * Tp * 32;
     const bf16 *Qrb = Qr + offR, *dOrb = dOr + offR;
     const uint16_t* mrow = maskQ + ((size_t)bh * nt + qtc) * nt * 64 + lane;      // LQ layout
     uint32_t mw = DROP ? mrow[0] : 0u;
@@ -538,11 +544,11 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
         const size_t m = (size_t)b * T + t;
         const float sc = (rowmask && rowmask[m] == 0.0f) ? 0.f : scale;     // blanked query rows pass no gradient to Q
 #pragma unroll
-        for (int g = 0; g < DKP / 8; ++g) {
+        for (int g = 0; g < DKB / 8; ++g) {
             bf16x4 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = (bf16)(dq[4 * g + j] * sc);
-            const int e0 = head * DKP + 8 * g + 4 * hh;
+            const int e0 = head * DKP + 32 * fb + 8 * g + 4 * hh;
             *reinterpret_cast<bf16x4*>(dqkv + m * lddqkv + e0) = v;
         }
     }

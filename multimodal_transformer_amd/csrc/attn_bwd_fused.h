@@ -58,7 +58,7 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
     const bool live = kt < nt;                          // idle waves stage, synchronise and take their share of the dQ reduction
     const int bh = blockIdx.x, b = bh / h, head = bh - b * h;
     const int Tp = nt * 32, HD = h * DKP;
-    const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp);
+    const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp, DKP);
     // dropout: this lane's words of the wave's row of mask blocks (attn_mask.h, LK layout: key on the lane), one per query tile, a tile ahead
     const uint16_t* mrow = maskK + ((size_t)bh * nt + (live ? kt : 0)) * nt * 64 + lane;
     uint32_t mw = DROP ? mrow[0] : 0u;

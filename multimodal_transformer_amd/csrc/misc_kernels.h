@@ -40,7 +40,7 @@ struct LayerLayout {
 inline LayerLayout make_layout(int d, int f, int h) {
     LayerLayout L;
     L.d = d; L.f = f; L.h = h; L.dk = d / h;
-    L.DKP = (L.dk <= 16) ? 16 : 32;
+    L.DKP = (L.dk <= 16) ? 16 : (L.dk <= 32 ? 32 : 64);
     L.HD = h * L.DKP; L.HDP = round_up(L.HD, 64);
     L.DP = round_up(d, 64); L.FP = round_up(f, 64);
     L.NQ = round_up(3 * L.HD, 64);

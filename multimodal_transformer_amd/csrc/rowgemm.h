@@ -400,8 +400,8 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             }
         } else if (EPI == EPI_FRAG) {
             const int HD = p.h * p.DKP;
-            const size_t szR = fragR_elems(p.Tp, p.DKP), szT = fragT_elems(p.Tp);
-            const int nred = p.DKP >> 2;                 // lanes per head (4 or 8), aligned groups
+            const size_t szR = fragR_elems(p.Tp, p.DKP), szT = fragT_elems(p.Tp, p.DKP);
+            const int nred = p.DKP >> 2;                 // lanes per head (4, 8 or 16), aligned groups
             const bool fastT = (p.T & 3) == 0;           // 4 consecutive windows of a tile row group share (batch, s, hh): 8-byte T stores
             const int cg = tid & 31, n = n0 + cg * 4, rbase = tid >> 5;
             const bool col_ok = n < p.nwhich * HD;
@@ -441,7 +441,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                     if (!fastT) {
                         bf16* dT = p.fragT[wi] + bh * szT;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) dT[fragT_index(t, e + i)] = o[i];
+                        for (int i = 0; i < 4; ++i) dT[fragT_index(t, e + i, p.Tp)] = o[i];
                     }
                     if (p.delta) {
 #pragma unroll
@@ -456,7 +456,8 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                 }
                 if (p.delta) {
                     part += __shfl_xor(part, 1); part += __shfl_xor(part, 2);
-                    if (nred == 8) part += __shfl_xor(part, 4);
+                    if (nred >= 8) part += __shfl_xor(part, 4);
+                    if (nred == 16) part += __shfl_xor(part, 8);
                     if (ok && e == 0) p.delta[(size_t)bh * p.Tp + t] = -part;      // stored negated (accumulator init of the backward)
                 }
             }
@@ -492,7 +493,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                         const int b = mg / p.T, t = mg - b * p.T;
                         const bool second = (t >> 3) & 1;                    // this row group is the j = 4..7 half of its piece
                         if (second && rg >= 2) continue;                     // written by row group rg-2 (same tile, same sequence)
-                        bf16* dst = p.fragT[wj] + (size_t)(b * p.h + hj) * szT + fragT_index(t, ej);
+                        bf16* dst = p.fragT[wj] + (size_t)(b * p.h + hj) * szT + fragT_index(t, ej, p.Tp);
                         bf16x4 o;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) o[i] = (bf16)Fs[(4 * rg + i) * ldf + c];

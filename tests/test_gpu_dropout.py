@@ -128,7 +128,8 @@ def test_module_train_mode_runs_and_reseeds(dev):
 @pytest.mark.parametrize("B,T,d,h,lengths,p", [(2, 300, 128, 8, [300, 170], 0.1),      # d_k 16, one-kernel backward
                                                 (2, 70, 256, 8, [70, 33], 0.1),          # d_k 32, two-kernel backward
                                                 (3, 33, 40, 4, [33, 20, 1], 0.25),       # d_k 10 (padded to 16), ragged tail tile
-                                                (1, 520, 128, 8, [520], 0.1)])           # 17 key tiles: two-kernel backward at d_k 16
+                                                (1, 520, 128, 8, [520], 0.1),            # 17 key tiles: two-kernel backward at d_k 16
+                                                (2, 70, 256, 4, [70, 41], 0.1)])         # d_k 64: two feature blocks
 def test_standalone_attention_train_mode_replay(dev, B, T, d, h, lengths, p):
     """attention() / MultiHeadedAttention outside the fused stack apply nn.Dropout to p_attn in train mode
     (transformer/MFT/multiTransformer.py:31-33): the stored bit masks (stream 0) are extracted and replayed through the oracle,

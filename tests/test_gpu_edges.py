@@ -64,6 +64,12 @@ def test_tile_boundaries(dev, B, T, d, h):
     _check_encoder(dev, d, h, 2, B, T, lengths, "edge:%dx%dx%d" % (B, T, d))
 
 
+def test_head_size_64(dev):
+    """d_model % h == 0 is all the reference asks (transformer/MFT/multiTransformer.py:39): h = 4 at d_model = 256 gives d_k = 64"""
+    _check_encoder(dev, 256, 4, 2, 2, 45, [45, 20], "edge:dk64")
+    _check_encoder(dev, 192, 4, 1, 2, 33, [33, 9], "edge:dk48")
+
+
 def test_long_sequence_eval_and_dropout_limit(dev):
     """T = 2500 runs in eval mode; train-mode attention dropout is limited to T <= 4096 (24-bit pair index) and says so"""
     from multimodal_transformer_amd import multiTransformer as MT
@@ -105,7 +111,7 @@ def test_refusals(dev):
     with pytest.raises((RuntimeError, NotImplementedError)):
         F.lstm_scan(torch.zeros(3, 2, 4 * 6, device=dev), torch.zeros(24, 6, device=dev))          # H % 4 != 0
     with pytest.raises((RuntimeError, NotImplementedError)):
-        F.sdpa(torch.zeros(1, 8, 8 * 80, device=dev), torch.zeros(1, 8, 640, device=dev), torch.zeros(1, 8, 640, device=dev), None, 8)  # d_k = 80 > 32
+        F.sdpa(torch.zeros(1, 8, 8 * 80, device=dev), torch.zeros(1, 8, 640, device=dev), torch.zeros(1, 8, 640, device=dev), None, 8)  # d_k = 80 > 64
 
 
 def test_encoder_gradients_share_one_flat_buffer(dev):
