@@ -10,8 +10,10 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="$REPO/bench.py"
-echo "== kernel-trace + stats of: python3 bench.py (default flags)"
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/stats.log || exit 1
+# the headline workload only (--no-full-model drops the whole-model / full-batch / MFT blocks, which launch the same kernels at other
+# sizes and would blur the per-kernel averages the roofline line is checked against)
+echo "== kernel-trace + stats of: python3 bench.py --no-full-model --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $BENCH --no-full-model --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log || exit 1
 SHORT="--steps 3 --warmup 1 --profile-steps 0 --no-graph --no-full-model --no-cpu-baseline"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY"; do
   name=$(echo $pass | tr ' ' '+')
