@@ -297,6 +297,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     from multimodal_transformer_amd import _lib
+    from multimodal_transformer_amd.functional import mse_sum_loss
     cfg = dict(WORKLOADS[args.workload])
     if args.batch > 0:
         cfg["B"] = args.batch
@@ -317,7 +318,7 @@ def main():
         for p in params:
             p.grad = None
         x.grad = None
-        loss = ((enc(x, mask) - tgt) ** 2).sum() / nvalid
+        loss = mse_sum_loss(enc(x, mask), tgt, nvalid)
         loss.backward()
 
     run = Runner(fwd_bwd, params, world, not args.no_graph, args.warmup)
@@ -382,7 +383,7 @@ def main():
         def model_step():
             for p in mparams:
                 p.grad = None
-            loss = ((model(xin, mask, lengths) - tgt1) ** 2).sum() / float(B * T)
+            loss = mse_sum_loss(model(xin, mask, lengths), tgt1, B * T)
             loss.backward()
 
         mrun = Runner(model_step, mparams, 1, not args.no_graph, 3)
@@ -417,7 +418,7 @@ def main():
         def pipe_step():
             for p in pparams:
                 p.grad = None
-            loss = ((pmodel(praw, [T] * B, mask) - ptgt) ** 2).sum() / float(B * T)
+            loss = mse_sum_loss(pmodel(praw, [T] * B, mask), ptgt, B * T)
             loss.backward()
 
         prun = Runner(pipe_step, pparams, 1, not args.no_graph, 3)
@@ -462,7 +463,7 @@ def main():
         def mft_step():
             for p in mparams2:
                 p.grad = None
-            loss = ((mmodel(xin2, mask2, [Tm] * Bm) - tgt2) ** 2).sum() / float(Bm * Tm)
+            loss = mse_sum_loss(mmodel(xin2, mask2, [Tm] * Bm), tgt2, Bm * Tm)
             loss.backward()
 
         nst2 = max(5, args.steps // 2)
@@ -491,7 +492,7 @@ def main():
             for p in params:
                 p.grad = None
             xf.grad = None
-            (((enc(xf, maskf) - tgtf) ** 2).sum() / float(Bf * T)).backward()
+            mse_sum_loss(enc(xf, maskf), tgtf, Bf * T).backward()
 
         frun = Runner(full_step, params, 1, not args.no_graph, 2)
         nf = max(5, args.steps // 2)
@@ -521,7 +522,7 @@ def main():
         def mft4_step():
             for p in p4:
                 p.grad = None
-            (((m4(x4, mask4, [T4] * B4) - tgt4) ** 2).sum() / float(B4 * T4)).backward()
+            mse_sum_loss(m4(x4, mask4, [T4] * B4), tgt4, B4 * T4).backward()
 
         n4 = 5
         r4 = Runner(mft4_step, p4, 1, not args.no_graph, 2)

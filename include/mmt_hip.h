@@ -162,6 +162,14 @@ int mmt_convpool_forward(const float* x, const float* weight, const float* bias,
 int mmt_convpool_backward(const float* x, const float* dout, const int32_t* argmax, float* dweight, float* dbias,
                           void* workspace, size_t workspace_bytes, int N, int W, int D, int F, mmt_stream_t stream);
 
+/* ---- Training loss and its gradient in one pass.
+ * Replaces criterion(output, target) / sum(lengths) and its autograd backward   transformer/SFT/train.py:133-139 (criterion :538)
+ * loss[0] = sum((pred - target)^2) * inv_denom (fp64 accumulation, deterministic);  dpred = 2 (pred - target) * inv_denom.
+ * pred, target, dpred: n fp32 (16-byte aligned); scratch: mmt_mse_sum_scratch_doubles(n) doubles; all on the device. */
+size_t mmt_mse_sum_scratch_doubles(size_t n);
+int mmt_mse_sum_forward(const float* pred, const float* target, float inv_denom, float* loss, float* dpred, double* scratch,
+                        size_t n, mmt_stream_t stream);
+
 /* ---- Concordance correlation coefficient per sequence, on the device.
  * Replaces eval_ccc + the per-sequence host loop of evaluate()     transformer/SFT/train.py:42-50, :236-238
  * pred, target: (B, T) fp32 row-major (the (B,T,1) valence tensors); lengths: B int32 on the device; sequence b uses its first

@@ -117,6 +117,16 @@ static int make_dims(EncDims& D, int B, int T, int d, int h, int f, int N) {
     D.M = B * T; D.MP = round_up(D.M, 64); D.M16 = round_up(D.M, 16);
     D.Tp = round_up(T, 32); D.nt = D.Tp / 32; D.G = (D.M + 31) / 32; D.GR = (D.M + MMT_ROWS - 1) / MMT_ROWS;
     D.L = make_layout(d, f, h);
+    {   // the row kernels keep a whole window tile in LDS: refuse here what their launches would refuse later (launch_rowchain /
+        // launch_rowgemm), so a shape fails at the workspace query and never half-way through a training step
+        const LayerLayout& L = D.L;
+        const int kmax = std::max(std::max(L.DP, L.FP), L.HDP), fw = std::max(128, L.DP);
+        const size_t bwd_chain = (size_t)MMT_ROWS * ((kmax + 8) * 2 + (fw + 4) * 4 * 2 + (L.DP + 4) * 4 + (L.FP + 8) * 2);
+        const size_t bwd_qkv = rowgemm_lds_bytes(EPI_LNBWD, false, L.NQ, L.DP);
+        if (bwd_chain > 160 * 1024 || bwd_qkv > 160 * 1024)
+            return fail(MMT_EUNSUPPORTED, "d_model %d / d_ff %d: a %d-window tile of the backward row kernels needs %zu B of LDS (160 KB per CU)",
+                        d, f, MMT_ROWS, std::max(bwd_chain, bwd_qkv));
+    }
     // weight-gradient split over windows: ONE launch covers every layer.  The launch deals (layer, split) units of `tpl` tiles
     // round-robin to the 8 XCDs (wgrad_kernel), and an XCD holds 32 CUs x 3 workgroups (48 KB of LDS each) at a time: pick the
     // split count that minimises (dispatch rounds on the fullest XCD) x (64-window chunks per workgroup + overhead).
@@ -270,50 +280,18 @@ static int launch_mask_gen(uint16_t* mq, uint16_t* mk, const EncDims& D, int nla
     return MMT_OK;
 }
 
-// Even spread of a grid that fits the chip in ONE round.  The dispatcher fills a CU with as many workgroups as its registers and
-// LDS admit before moving on: 1024 workgroups of attn_fwd_kernel (5 fit per CU) land as 5 on some CUs and 3 or none on others, and
-// the launch lasts as long as its fullest CU (measured with in-kernel stamps: wave lifetimes 31k..56k cycles, exits spread over
-// 11 us of a 25 us launch).  Requesting unused dynamic LDS so that exactly ceil(grid / CUs) workgroups fit per CU makes the
-// placement even.  Returns the dynamic LDS bytes to request (0: the grid needs several rounds anyway, or cannot be capped).
-static size_t balance_lds(int grid_wgs, size_t static_lds) {
-    static int cus = 0;
-    if (!cus) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = -1; }
-    if (cus <= 0 || getenv("MMT_NO_BALANCE")) return 0;
-    const int per_cu = (grid_wgs + cus - 1) / cus;
-    if (per_cu > 8) return 0;                                   // beyond any residency limit: several rounds
-    const size_t share = ((size_t)160 * 1024 / per_cu) & ~(size_t)255;
-    if (share <= static_lds + 256) return 0;
-    const size_t next = ((size_t)160 * 1024 / (per_cu + 1));    // must exclude per_cu + 1 workgroups
-    size_t dyn = share - static_lds;
-    if (static_lds + dyn <= next) return 0;
-    return dyn;
-}
-template <typename K> static int allow_big_lds(K kernel, int static_lds) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - static_lds) == hipSuccess ? MMT_OK
-           : fail(MMT_EHIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-}
-
 // `drop`: the layer's attention dropout (thr16 == 0: off); maskQ: its lane words, written by launch_mask_gen
 static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* VT, bf16* ctx, float* lse,
                            const EncDims& D, hipStream_t st, DropCfg drop = no_drop(), const uint16_t* maskQ = nullptr) {
     dim3 grid(attn_grid((D.nt + 3) / 4, D.B * D.h));
     if (drop.thr16 && !maskQ) return fail(MMT_EINVAL, "attention dropout without a mask buffer");
-    static bool big = false;
-    if (!big) {
-        int rc2;
-        if ((rc2 = allow_big_lds(&attn_fwd_kernel<16, true>, 6144)) || (rc2 = allow_big_lds(&attn_fwd_kernel<16, false>, 6144)) ||
-            (rc2 = allow_big_lds(&attn_fwd_kernel<32, true>, 8192)) || (rc2 = allow_big_lds(&attn_fwd_kernel<32, false>, 8192)) ||
-            (rc2 = allow_big_lds(&attn_fwd_kernel<64, true>, 12288)) || (rc2 = allow_big_lds(&attn_fwd_kernel<64, false>, 12288))) return rc2;
-        big = true;
-    }
-    const size_t bal = balance_lds((int)grid.x, (size_t)2 * (DKP * 4 + 128) * 16);      // the kernel's static LDS: two staging slots
     ProfScope prof(S_ATTN_FWD, st);
 #define MMT_FWD(dkp, dr) for (int fb = 0; fb < (dkp + 31) / 32; ++fb) \
-        hipLaunchKernelGGL((attn_fwd_kernel<dkp, dr>), grid, dim3(MMT_THREADS), bal, st, QR, KR, VT, ctx, lse, \
+        hipLaunchKernelGGL((attn_fwd_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, lse, \
                            D.h, D.T, D.nt, D.B * D.h, D.L.HDP, maskQ, drop.scale, fb)
 #ifdef MMT_ABLATIONS
     static const int abl = getenv("MMT_ABL") ? atoi(getenv("MMT_ABL")) : 0;
-#define MMT_FWD_A(a) hipLaunchKernelGGL((attn_fwd_kernel<16, true, a>), grid, dim3(MMT_THREADS), (a == 6 ? (allow_big_lds(&attn_fwd_kernel<16, true, 6>, 6144), bal) : 0), st, QR, KR, VT, ctx, lse, \
+#define MMT_FWD_A(a) hipLaunchKernelGGL((attn_fwd_kernel<16, true, a>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, lse, \
                                         D.h, D.T, D.nt, D.B * D.h, D.L.HDP, maskQ, drop.scale, 0)
     if (abl && DKP == 16 && drop.thr16) {
         switch (abl) { case 1: MMT_FWD_A(1); break; case 2: MMT_FWD_A(2); break; case 3: MMT_FWD_A(3); break; case 4: MMT_FWD_A(4); break;
@@ -1182,6 +1160,21 @@ extern "C" int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* cha
     return MMT_OK;
 }
 
+
+// ------------------------------------------------------------------------------------ loss
+extern "C" size_t mmt_mse_sum_scratch_doubles(size_t n) { return (size_t)grid_for(n, 1024); }
+
+extern "C" int mmt_mse_sum_forward(const float* pred, const float* target, float inv_denom, float* loss, float* dpred, double* scratch,
+                                   size_t n, mmt_stream_t stream) {
+    if (!pred || !target || !loss || !dpred || !scratch) return fail(MMT_EINVAL, "null pointer argument");
+    if (n == 0) return fail(MMT_EINVAL, "empty loss");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int g = grid_for(n, 1024);
+    hipLaunchKernelGGL(mse_sum_partial_kernel, dim3(g), dim3(256), 0, st, pred, target, inv_denom, dpred, scratch, n);
+    hipLaunchKernelGGL(mse_sum_final_kernel, dim3(1), dim3(256), 0, st, scratch, g, inv_denom, loss);
+    LAUNCH_CHECK("mse_sum kernels");
+    return MMT_OK;
+}
 
 // ------------------------------------------------------------------------------------ metric
 extern "C" int mmt_ccc_forward(const float* pred, const float* target, const int32_t* lengths, double* ccc, int B, int T, mmt_stream_t stream) {

@@ -436,3 +436,45 @@ __global__ __launch_bounds__(256) void ccc_kernel(const float* __restrict__ pred
         out[b] = (n < 2) ? __builtin_nan("") : 2.0 * cov / (vt + vp + (mp - mt) * (mp - mt));
     }
 }
+
+
+// Training loss of the reference (transformer/SFT/train.py:133-137, criterion :538): MSELoss(reduction='sum')(out, target) divided by
+// the number of valid windows, and its gradient 2 (out - target) / denom, in one pass (torch would run sub, pow, sum, div and four
+// backward kernels).  Partial sums in fp64 per workgroup, summed in a fixed order by a second tiny launch: deterministic.
+__global__ __launch_bounds__(256) void mse_sum_partial_kernel(const float* __restrict__ pred, const float* __restrict__ target, float inv_denom,
+                                                              float* __restrict__ dpred, double* __restrict__ part, size_t n) {
+    __shared__ double red[256];
+    double acc = 0;
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 p = reinterpret_cast<const f32x4*>(pred)[i], t = reinterpret_cast<const f32x4*>(target)[i];
+        const f32x4 d = p - t;
+        acc += (double)d[0] * d[0] + (double)d[1] * d[1] + (double)d[2] * d[2] + (double)d[3] * d[3];
+        reinterpret_cast<f32x4*>(dpred)[i] = d * (2.0f * inv_denom);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = (n4 << 2) + threadIdx.x;
+        const float d = pred[i] - target[i];
+        acc += (double)d * d;
+        dpred[i] = d * (2.0f * inv_denom);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void mse_sum_final_kernel(const double* __restrict__ part, int nparts, float inv_denom, float* __restrict__ loss) {
+    __shared__ double red[256];
+    double acc = 0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += part[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(red[0] * (double)inv_denom);
+}

@@ -413,6 +413,37 @@ def mfn_mem_scan(apre, chat, Wm, W2, b2, dropout_p=0.0, seed=0):
     return _MfnMemScanFn.apply(apre, chat, Wm, W2, b2, float(dropout_p), int(seed))
 
 
+class _MseSumLossFn(torch.autograd.Function):
+    """loss = sum((pred - target)^2) / denom and its gradient in one pass — the reference's per-batch loss
+    (transformer/SFT/train.py:133-137: MSELoss(reduction='sum') divided by sum(lengths))."""
+
+    @staticmethod
+    def forward(ctx, pred, target, denom):
+        lib = _lib.load()
+        _lib.require_hip(pred, target)
+        p_, t_ = _f32c(pred), _f32c(target)
+        if p_.shape != t_.shape:
+            raise ValueError("mse_sum_loss: pred %s and target %s differ in shape" % (tuple(pred.shape), tuple(target.shape)))
+        n = p_.numel()
+        loss = torch.empty((), dtype=torch.float32, device=p_.device)
+        dpred = torch.empty_like(p_)
+        scratch = torch.empty(lib.mmt_mse_sum_scratch_doubles(n), dtype=torch.float64, device=p_.device)
+        _lib.check(lib.mmt_mse_sum_forward(_lib.ptr(p_), _lib.ptr(t_), 1.0 / float(denom), _lib.ptr(loss), _lib.ptr(dpred), _lib.ptr(scratch),
+                                           n, _lib.stream_ptr()))
+        ctx.save_for_backward(dpred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g, None, None
+
+
+def mse_sum_loss(pred, target, denom):
+    """sum((pred - target)^2) / denom with the gradient produced in the same pass (train-step semantics of the reference)."""
+    return _MseSumLossFn.apply(pred, target, float(denom))
+
+
 def check_device_errors():
     """Synchronise and raise if an asynchronous kernel reported an error through its device error word (mmt_hip.h)."""
     _lib.ERRORS.check()

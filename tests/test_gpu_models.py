@@ -202,6 +202,27 @@ def test_multi_transformer_golden(dev):
     _check_model(dev, fx, model, lambda mask: model(ins, mask, lengths), "model_mft_avl", lengths, 50)
 
 
+def test_mse_sum_loss_and_gradient(dev):
+    """fused training loss (mmt_mse_sum_forward) = MSELoss(reduction='sum') / sum(lengths) of the reference's train loop
+    (transformer/SFT/train.py:133-139), value and gradient, incl. a size that is not a multiple of 4 and an upstream scale"""
+    from multimodal_transformer_amd import functional as F
+    for shape, denom in [((7, 33, 1), 190.0), ((32, 500, 128), 16000.0), ((3, 5), 1.0)]:
+        p = R.gen_uniform("mse:p", shape, 3)
+        t = R.gen_uniform("mse:t", shape, 3)
+        pd = p.double().requires_grad_(True)
+        ref = torch.nn.MSELoss(reduction="sum")(pd, t.double()) / denom
+        (3.0 * ref).backward()
+        pg = p.to(dev).requires_grad_(True)
+        got = F.mse_sum_loss(pg, t.to(dev), denom)
+        (3.0 * got).backward()
+        assert abs(got.item() - ref.item()) <= 2e-6 * abs(ref.item()), (got.item(), ref.item())
+        assert rel_l2(pg.grad.cpu().double(), pd.grad) < 1e-6
+        # deterministic: same bits on a second call
+        assert F.mse_sum_loss(pg, t.to(dev), denom).item() == got.item()
+    with pytest.raises(ValueError):
+        F.mse_sum_loss(torch.zeros(2, 3, device=dev), torch.zeros(3, 2, device=dev), 1.0)
+
+
 def test_batched_ccc_on_device(dev):
     """device-side per-sequence CCC (mmt_ccc_forward) vs the values the reference's eval_ccc gave for the same rows
     (fixture `batching`, generated from transformer/SFT/train.py:42-50) and vs the numpy restatement at a large size"""
