@@ -109,6 +109,29 @@ enum { ASRC_GLOBAL = 0, ASRC_X = 1, ASRC_A2 = 2 };           // where the A oper
 enum { KEEP_X = 1, KEEP_A2 = 2, RES_X = 4 };                  // epilogue: also write fp32 to Xs / bf16 to A2; residual from Xs
 struct RowSmem { bf16* As; float* Fs; float* Gs; float* Xs; bf16* A2; int ldf; int ldx; int lda2; };
 
+// (sequence, window) of row `row` of a tile whose first row is window t0 of sequence b0.  An integer division by a run-time
+// divisor is ~40 vector instructions; these kernels are bound by instruction issue and used to pay one per epilogue task.  A tile
+// is MMT_ROWS consecutive rows: with T >= MMT_ROWS it crosses at most one sequence boundary.
+struct SeqPos { int b, t; };
+__device__ __forceinline__ SeqPos seq_pos(int b0, int t0, int row, int T) {
+    SeqPos sp;
+    int t = t0 + row;
+    if (T >= MMT_ROWS) { const bool over = t >= T; sp.b = b0 + (over ? 1 : 0); sp.t = over ? t - T : t; }
+    else { const int q = t / T; sp.b = b0 + q; sp.t = t - q * T; }
+    return sp;
+}
+// which of the (up to three) stacked matrices column n belongs to, its head and feature: HD = h * DKP, DKP a power of two
+struct ColPos { int wi, rem, head, e; };
+__device__ __forceinline__ ColPos col_pos(int n, int HD, int DKP) {
+    ColPos cp;
+    cp.wi = (n >= HD ? 1 : 0) + (n >= 2 * HD ? 1 : 0);
+    cp.rem = n - cp.wi * HD;
+    const int sh = __builtin_ctz((unsigned)DKP);
+    cp.head = cp.rem >> sh;
+    cp.e = cp.rem & (DKP - 1);
+    return cp;
+}
+
 template <int EPI, bool LNPRO, int ASRC, int KEEP>
 __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowSmem& sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -146,12 +169,13 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     } else if (LNPRO) {
         if (ASRC == ASRC_GLOBAL) {
             const float* A = static_cast<const float*>(p.A);
-            const int k4 = KP >> 2;
-            for (int idx = tid; idx < ROWS * k4; idx += MMT_RTHREADS) {
-                const int row = idx / k4, c = (idx - row * k4) * 4, m = m0 + row;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (m < M && c < K) v = *reinterpret_cast<const f32x4*>(A + (size_t)m * p.lda + c);
-                *reinterpret_cast<f32x4*>(Fs + row * ldf + c) = v;
+            for (int row = tid >> 4; row < ROWS; row += MMT_RTHREADS / 16) {          // 16 lanes x 16 bytes along a row (KP % 64 == 0)
+                const int m = m0 + row;
+                for (int c = (tid & 15) * 4; c < KP; c += 64) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (m < M && c < K) v = *reinterpret_cast<const f32x4*>(A + (size_t)m * p.lda + c);
+                    *reinterpret_cast<f32x4*>(Fs + row * ldf + c) = v;
+                }
             }
             __syncthreads();
         }
@@ -187,9 +211,9 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         }
     } else if (ASRC == ASRC_X) {
         // fp32 tile kept by the previous stage -> bf16 (optionally through the dropout mask of index m*KP + k)
-        const int k4 = KP >> 2;
-        for (int idx = tid; idx < ROWS * k4; idx += MMT_RTHREADS) {
-            const int row = idx / k4, c = (idx - row * k4) * 4, m = m0 + row;
+        for (int row = tid >> 4; row < ROWS; row += MMT_RTHREADS / 16)
+        for (int c = (tid & 15) * 4; c < KP; c += 64) {
+            const int m = m0 + row;
             bf16x4 o = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
             if (m < M && c < K) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(Xs + row * sm.ldx + c);
@@ -207,9 +231,9 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         }
     } else if (p.a_bf16) {
         const bf16* A = static_cast<const bf16*>(p.A);
-        const int k8 = KP >> 3;
-        for (int idx = tid; idx < ROWS * k8; idx += MMT_RTHREADS) {
-            const int row = idx / k8, c = (idx - row * k8) * 8, m = m0 + row;
+        for (int row = tid >> 3; row < ROWS; row += MMT_RTHREADS / 8)               // 8 lanes x 16 bytes along a row
+        for (int c = (tid & 7) * 8; c < KP; c += 64) {
+            const int m = m0 + row;
             bf16x8 v;
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = (bf16)0.f;
@@ -218,9 +242,9 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         }
     } else {
         const float* A = static_cast<const float*>(p.A);
-        const int k4 = KP >> 2;
-        for (int idx = tid; idx < ROWS * k4; idx += MMT_RTHREADS) {
-            const int row = idx / k4, c = (idx - row * k4) * 4, m = m0 + row;
+        for (int row = tid >> 4; row < ROWS; row += MMT_RTHREADS / 16)
+        for (int c = (tid & 15) * 4; c < KP; c += 64) {
+            const int m = m0 + row;
             bf16x4 o = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
             if (m < M && c < K) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(A + (size_t)m * p.lda + c);
@@ -241,9 +265,9 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     PHASE(0);                                                 // A tile staged (LayerNorm prologue included)
 
     if (p.A_out) {    // row-major copy of the bf16 tile (16-byte pieces, whole rows contiguous)
-        const int k8 = KP >> 3;
-        for (int idx = tid; idx < ROWS * k8; idx += MMT_RTHREADS) {
-            const int row = idx / k8, c = (idx - row * k8) * 8, m = m0 + row;
+        for (int row = tid >> 3; row < ROWS; row += MMT_RTHREADS / 8)
+        for (int c = (tid & 7) * 8; c < KP; c += 64) {
+            const int m = m0 + row;
             if (m < M) *reinterpret_cast<bf16x8*>(p.A_out + (size_t)m * p.lda_out + c) = *reinterpret_cast<const bf16x8*>(As + row * lda_s + c);
         }
     }
@@ -405,8 +429,10 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             const bool fastT = (p.T & 3) == 0;           // 4 consecutive windows of a tile row group share (batch, s, hh): 8-byte T stores
             const int cg = tid & 31, n = n0 + cg * 4, rbase = tid >> 5;
             const bool col_ok = n < p.nwhich * HD;
-            int wi = 0, rem = 0, head = 0, e = 0;
-            if (col_ok) { wi = n / HD; rem = n - wi * HD; head = rem / p.DKP; e = rem - head * p.DKP; }
+            const ColPos cp = col_pos(col_ok ? n : 0, HD, p.DKP);
+            const int wi = cp.wi, rem = cp.rem, head = cp.head, e = cp.e;
+            // first row of the tile in (sequence, window) form: one wave-uniform division per stage
+            const int tb0 = __builtin_amdgcn_readfirstlane(m0 / p.T), tt0 = m0 - tb0 * p.T;
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
             if (col_ok && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
             // phase 1: all global loads of the 4 tasks
@@ -429,9 +455,9 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                 int bh = 0, t = 0;
                 bf16x4 o = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
                 if (ok) {
-                    const int b = m / p.T;
-                    t = m - b * p.T;
-                    bh = b * p.h + head;
+                    const SeqPos sp = seq_pos(tb0, tt0, row, p.T);
+                    t = sp.t;
+                    bh = sp.b * p.h + head;
                     f32x4 v = *reinterpret_cast<const f32x4*>(Fs + row * ldf + cg * 4);
                     v += bias4;
                     v *= sc[it];
@@ -471,8 +497,10 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                 for (int it = 0; it < (MMT_ROWS * 16 + MMT_RTHREADS - 1) / MMT_RTHREADS; ++it) {
                     const int q = tid + it * MMT_RTHREADS, rr = q % MMT_ROWS, cc = q / MMT_ROWS, nn = n0 + 8 * cc, mm = m0 + rr;
                     if (cc < 16 && nn < p.nwhich * HD && mm < M) {
-                        const int wj = nn / HD, rj = nn - wj * HD, hj = rj / p.DKP, ej = rj - hj * p.DKP;
-                        const int b = mm / p.T, t = mm - b * p.T;
+                        const ColPos cj = col_pos(nn, HD, p.DKP);
+                        const int wj = cj.wi, hj = cj.head, ej = cj.e;
+                        const SeqPos sp = seq_pos(tb0, tt0, rr, p.T);
+                        const int b = sp.b, t = sp.t;
                         const f32x4 lo = *reinterpret_cast<const f32x4*>(Fs + rr * ldf + 8 * cc);
                         const f32x4 hi = *reinterpret_cast<const f32x4*>(Fs + rr * ldf + 8 * cc + 4);
                         bf16x8 o;
@@ -485,12 +513,14 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                 //  t..t+3 and t+8..t+11, i.e. row groups rg and rg+2 of this tile when both lie in it and in the sequence
                 const int c = tid & 127, nn = n0 + c;
                 if (nn < p.nwhich * HD) {
-                    const int wj = nn / HD, rj = nn - wj * HD, hj = rj / p.DKP, ej = rj - hj * p.DKP;
+                    const ColPos cj = col_pos(nn, HD, p.DKP);
+                    const int wj = cj.wi, hj = cj.head, ej = cj.e;
 #pragma unroll
                     for (int it = 0; it < (MMT_ROWS / 4) / (MMT_RTHREADS / 128); ++it) {
                         const int rg = (tid >> 7) + (MMT_RTHREADS / 128) * it, mg = m0 + 4 * rg;
                         if (mg >= M) continue;
-                        const int b = mg / p.T, t = mg - b * p.T;
+                        const SeqPos sp = seq_pos(tb0, tt0, 4 * rg, p.T);
+                        const int b = sp.b, t = sp.t;
                         const bool second = (t >> 3) & 1;                    // this row group is the j = 4..7 half of its piece
                         if (second && rg >= 2) continue;                     // written by row group rg-2 (same tile, same sequence)
                         bf16* dst = p.fragT[wj] + (size_t)(b * p.h + hj) * szT + fragT_index(t, ej, p.Tp);

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Developer tool: per-phase cycle split of the row-GEMM stages (needs a library built with -DMMT_PHASE_TIMING:
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DMMT_PHASE_TIMING -o scratch_ab/libmmt_phase.so multimodal_transformer_amd/csrc/api.hip
-and copied over multimodal_transformer_amd/libmmt_hip.so on the GPU box)."""
+"""Developer tool: per-phase cycle split of the row-GEMM stages.  Needs tools/bin/libmmt_phase.so:
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DMMT_PHASE_TIMING -o tools/bin/libmmt_phase.so multimodal_transformer_amd/csrc/api.hip"""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["MMT_LIB_PATH"] = os.path.join(ROOT, "tools", "bin", "libmmt_phase.so")
+sys.path.insert(0, ROOT)
 import torch
 from multimodal_transformer_amd import multiTransformer as MT, _lib
 B, T, d, h = (int(v) for v in (sys.argv[1:5] if len(sys.argv) > 4 else (32, 500, 128, 8)))
