@@ -147,19 +147,42 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     const int l15 = lane & 15, lq = lane >> 4;
     PHASE_DECL
 
-    // W fragments of the first chunk's first two k-blocks go in flight NOW: their L2 latency overlaps the A-tile staging
-    // (b*1 / n*1 — the wave's second 16-column MFMA tile — exist only with four waves per workgroup, MMT_WNT == 2)
-    bf16x8 b00, b01, b10, b11, n00, n01, n10, n11;
-    {
-        const int nb = wave * MMT_WCOLS;
-        const bf16* wrow0 = p.W + (size_t)((nb < NP ? nb : 0) + l15) * KP + 8 * lq;
-        const bf16* wrow1 = wrow0 + (size_t)16 * KP;
-        b00 = *reinterpret_cast<const bf16x8*>(wrow0); b10 = *reinterpret_cast<const bf16x8*>(wrow0 + 32);
-        if (MMT_WNT == 2) { b01 = *reinterpret_cast<const bf16x8*>(wrow1); b11 = *reinterpret_cast<const bf16x8*>(wrow1 + 32); }
-        n00 = b00; n01 = b01; n10 = b10; n11 = b11;
-        if (KP > 64) {
-            n00 = *reinterpret_cast<const bf16x8*>(wrow0 + 64); n10 = *reinterpret_cast<const bf16x8*>(wrow0 + 96);
-            if (MMT_WNT == 2) { n01 = *reinterpret_cast<const bf16x8*>(wrow1 + 64); n11 = *reinterpret_cast<const bf16x8*>(wrow1 + 96); }
+    // W fragments (straight from L2, ~1k cycles away) travel through a ring of PFD k-blocks per wave.  The first PFD blocks of the
+    // first chunk go in flight NOW: their latency overlaps the A-tile staging.  The stand-alone LayerNorm-backward instance
+    // (bwd_qkv: K = 3 h d_k, six k-blocks at d_model = 128, 58 VGPRs) keeps four blocks in flight (six spill) — with two, four L2 round trips
+    // per tile were exposed; the chained kernels sit at the 128-VGPR cap and keep two.
+    constexpr int PFD = (EPI == EPI_LNBWD && ASRC == ASRC_GLOBAL && KEEP == 0) ? 4 : 2;
+    bf16x8 wf[PFD][2][MMT_WNT];                                   // [slot][k half: +0 / +32][16-column tile of the wave]
+    auto w_load = [&](int slot, int nb, int kb) {                 // slot and the guard are compile-time / wave-uniform
+        const bf16* wr = p.W + (size_t)(nb + l15) * KP + 8 * lq + kb;
+#pragma unroll
+        for (int b = 0; b < MMT_WNT; ++b) {
+            wf[slot][0][b] = *reinterpret_cast<const bf16x8*>(wr + (size_t)16 * b * KP);
+            wf[slot][1][b] = *reinterpret_cast<const bf16x8*>(wr + (size_t)16 * b * KP + 32);
+        }
+    };
+    auto w_prime = [&](int nb) {
+#pragma unroll
+        for (int j = 0; j < PFD; ++j) if (64 * j < KP) w_load(j, nb, 64 * j);
+    };
+    if (wave * MMT_WCOLS < NP) w_prime(wave * MMT_WCOLS);
+
+    // LayerNorm-backward epilogue operands (the layer input x and the residual gradient of this thread's row pieces): also issued
+    // now, not inside the epilogue where each of three dependent global loads used to be waited for in turn
+    constexpr int LNB_CH = 5;                                     // row pieces per thread; NP <= 320 is all the LDS admits (api.hip make_dims)
+    f32x4 lx[LNB_CH], lr[LNB_CH];                                 // (dead in the other instances)
+    float lmean = 0.f, lrstd = 0.f;
+    if (EPI == EPI_LNBWD) {
+        const int row = tid / MMT_RTPR, j = tid % MMT_RTPR, m = m0 + row;
+        if (m < M) { lmean = p.st[2 * (size_t)m]; lrstd = p.st[2 * (size_t)m + 1]; }
+#pragma unroll
+        for (int i = 0; i < LNB_CH; ++i) {
+            const int c = j * 4 + i * 4 * MMT_RTPR;
+            lx[i] = f32x4{0.f, 0.f, 0.f, 0.f}; lr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < M && c < p.d_real) {
+                lx[i] = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + c);
+                if (p.dres) lr[i] = *reinterpret_cast<const f32x4*>(p.dres + (size_t)m * p.lddres + c);
+            }
         }
     }
 
@@ -282,41 +305,33 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int b = 0; b < MMT_WNT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const bf16* wrow0 = p.W + (size_t)(nb + l15) * KP + 8 * lq;
-            const bf16* wrow1 = wrow0 + (size_t)16 * KP;
             const bf16* arow0 = As + l15 * lda_s + 8 * lq;
             const bf16* arow1 = arow0 + 16 * lda_s;
-            if (n0 > 0) {                    // (chunk 0's first fragments were issued before the A-tile staging)
-                b00 = *reinterpret_cast<const bf16x8*>(wrow0); b10 = *reinterpret_cast<const bf16x8*>(wrow0 + 32);
-                if (MMT_WNT == 2) { b01 = *reinterpret_cast<const bf16x8*>(wrow1); b11 = *reinterpret_cast<const bf16x8*>(wrow1 + 32); }
-            }
-            for (int kb = 0; kb < KP; kb += 64) {
-                if (kb + 64 < KP && (kb > 0 || n0 > 0)) {   // next k-block's W fragments in flight behind this block's MFMAs
-                    n00 = *reinterpret_cast<const bf16x8*>(wrow0 + kb + 64);
-                    n10 = *reinterpret_cast<const bf16x8*>(wrow0 + kb + 96);
-                    if (MMT_WNT == 2) {
-                        n01 = *reinterpret_cast<const bf16x8*>(wrow1 + kb + 64);
-                        n11 = *reinterpret_cast<const bf16x8*>(wrow1 + kb + 96);
+            for (int kb0 = 0; kb0 < KP; kb0 += 64 * PFD) {
+#pragma unroll
+                for (int j = 0; j < PFD; ++j) {
+                    const int kb = kb0 + 64 * j;
+                    if (kb >= KP) break;                          // wave-uniform
+                    const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(arow0 + kb);
+                    const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(arow0 + kb + 32);
+#pragma unroll
+                    for (int b = 0; b < MMT_WNT; ++b) acc[0][b] = mfma16(a00, wf[j][0][b], acc[0][b]);
+                    if (MT == 2) {
+                        const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(arow1 + kb);
+#pragma unroll
+                        for (int b = 0; b < MMT_WNT; ++b) acc[MT - 1][b] = mfma16(a01, wf[j][0][b], acc[MT - 1][b]);
                     }
+#pragma unroll
+                    for (int b = 0; b < MMT_WNT; ++b) acc[0][b] = mfma16(a10, wf[j][1][b], acc[0][b]);
+                    if (MT == 2) {
+                        const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(arow1 + kb + 32);
+#pragma unroll
+                        for (int b = 0; b < MMT_WNT; ++b) acc[MT - 1][b] = mfma16(a11, wf[j][1][b], acc[MT - 1][b]);
+                    }
+                    if (kb + 64 * PFD < KP) w_load(j, nb, kb + 64 * PFD);        // the slot just consumed takes the block PFD ahead
                 }
-                const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(arow0 + kb);
-                const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(arow0 + kb + 32);
-                acc[0][0] = mfma16(a00, b00, acc[0][0]);
-                if (MMT_WNT == 2) acc[0][MMT_WNT - 1] = mfma16(a00, b01, acc[0][MMT_WNT - 1]);
-                if (MT == 2) {
-                    const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(arow1 + kb);
-                    acc[MT - 1][0] = mfma16(a01, b00, acc[MT - 1][0]);
-                    if (MMT_WNT == 2) acc[MT - 1][MMT_WNT - 1] = mfma16(a01, b01, acc[MT - 1][MMT_WNT - 1]);
-                }
-                acc[0][0] = mfma16(a10, b10, acc[0][0]);
-                if (MMT_WNT == 2) acc[0][MMT_WNT - 1] = mfma16(a10, b11, acc[0][MMT_WNT - 1]);
-                if (MT == 2) {
-                    const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(arow1 + kb + 32);
-                    acc[MT - 1][0] = mfma16(a11, b10, acc[MT - 1][0]);
-                    if (MMT_WNT == 2) acc[MT - 1][MMT_WNT - 1] = mfma16(a11, b11, acc[MT - 1][MMT_WNT - 1]);
-                }
-                b00 = n00; b01 = n01; b10 = n10; b11 = n11;
             }
+            if (nb + 128 < NP) w_prime(nb + 128);                 // next chunk's first blocks travel behind this chunk's epilogue
             const int cbase = ((EPI == EPI_LNBWD) ? nb : wave * MMT_WCOLS) + l15;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -550,27 +565,31 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         const int row = tid / TPR, j = tid % TPR, m = m0 + row;
         float* cr = Fs + row * ldf;          // dxn = grad wrt LayerNorm output (fp32)
         float* gr = Gs + row * (NP + 4);
-        float mean = 0.f, rstd = 0.f;
-        if (m < M) { mean = p.st[2 * (size_t)m]; rstd = p.st[2 * (size_t)m + 1]; }
+        const float mean = lmean, rstd = lrstd;
         {
         float s1 = 0.f, s2 = 0.f;
-        for (int c = j * 4; c < NP; c += 4 * TPR) {
+#pragma unroll
+        for (int i = 0; i < LNB_CH; ++i) {
+            const int c = j * 4 + i * 4 * TPR;
+            if (c >= NP) break;
             f32x4 g = {0.f, 0.f, 0.f, 0.f}, xh = {0.f, 0.f, 0.f, 0.f};
             if (m < M && c < d) {
                 f32x4 dy = *reinterpret_cast<const f32x4*>(cr + c);
-                f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + c);
+                const f32x4 xv = lx[i];
                 f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_a + c);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    xh[i] = (xv[i] - mean) * rstd;
-                    g[i] = dy[i] * a[i];
-                    s1 += g[i];
-                    s2 += g[i] * xh[i];
+                for (int e = 0; e < 4; ++e) {
+                    xh[e] = (xv[e] - mean) * rstd;
+                    g[e] = dy[e] * a[e];
+                    s1 += g[e];
+                    s2 += g[e] * xh[e];
                 }
                 f32x4 gx;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) gx[i] = dy[i] * xh[i];
+                for (int e = 0; e < 4; ++e) gx[e] = dy[e] * xh[e];
                 *reinterpret_cast<f32x4*>(gr + c) = gx;
+                lx[i] = xh;                              // second pass needs x-hat and g = dy * a, not x and dy
+                lr[i] += g * rstd;                       // dres + rstd * g
             } else {
                 *reinterpret_cast<f32x4*>(cr + c) = g;
                 *reinterpret_cast<f32x4*>(gr + c) = g;
@@ -581,18 +600,13 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         if (TPR == 16) { s1 += __shfl_xor(s1, 8); s2 += __shfl_xor(s2, 8); }
         if (m < M) {
             const float sigma = 1.0f / rstd - p.eps;
-            const float k1 = s1 / (float)d, k2 = s2 / ((float)(d - 1) * sigma);
-            for (int c = j * 4; c < d; c += 4 * TPR) {
-                f32x4 dy = *reinterpret_cast<const f32x4*>(cr + c);
-                f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + c);
-                f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_a + c);
-                f32x4 o;
+            const float k1 = rstd * (s1 / (float)d), k2 = s2 / ((float)(d - 1) * sigma);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float xh = (xv[i] - mean) * rstd;
-                    o[i] = rstd * (dy[i] * a[i] - k1) - k2 * xh;
-                }
-                if (p.dres) { f32x4 r = *reinterpret_cast<const f32x4*>(p.dres + (size_t)m * p.lddres + c); o += r; }
+            for (int i = 0; i < LNB_CH; ++i) {
+                const int c = j * 4 + i * 4 * TPR;
+                if (c >= d) break;
+                // dx = rstd * (dy a - s1/d) - k2 x-hat (+ residual gradient)
+                const f32x4 o = lr[i] - k1 - lx[i] * k2;
                 *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + c) = o;
                 if (KEEP & KEEP_X) *reinterpret_cast<f32x4*>(Xs + row * sm.ldx + c) = o;
             }
