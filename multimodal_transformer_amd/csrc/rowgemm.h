@@ -149,9 +149,9 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
 
     // W fragments (straight from L2, ~1k cycles away) travel through a ring of PFD k-blocks per wave.  The first PFD blocks of the
     // first chunk go in flight NOW: their latency overlaps the A-tile staging.  The stand-alone LayerNorm-backward instance
-    // (bwd_qkv: K = 3 h d_k, six k-blocks at d_model = 128, 58 VGPRs) keeps four blocks in flight (six spill) — with two, four L2 round trips
+    // (bwd_qkv: K = 3 h d_k, six k-blocks at d_model = 128, 58 VGPRs) keeps six blocks in flight — with two, four L2 round trips
     // per tile were exposed; the chained kernels sit at the 128-VGPR cap and keep two.
-    constexpr int PFD = (EPI == EPI_LNBWD && ASRC == ASRC_GLOBAL && KEEP == 0) ? 4 : 2;
+    constexpr int PFD = (EPI == EPI_LNBWD && ASRC == ASRC_GLOBAL && KEEP == 0) ? 6 : 2;
     bf16x8 wf[PFD][2][MMT_WNT];                                   // [slot][k half: +0 / +32][16-column tile of the wave]
     auto w_load = [&](int slot, int nb, int kb) {                 // slot and the guard are compile-time / wave-uniform
         const bf16* wr = p.W + (size_t)(nb + l15) * KP + 8 * lq + kb;
@@ -166,25 +166,6 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         for (int j = 0; j < PFD; ++j) if (64 * j < KP) w_load(j, nb, 64 * j);
     };
     if (wave * MMT_WCOLS < NP) w_prime(wave * MMT_WCOLS);
-
-    // LayerNorm-backward epilogue operands (the layer input x and the residual gradient of this thread's row pieces): also issued
-    // now, not inside the epilogue where each of three dependent global loads used to be waited for in turn
-    constexpr int LNB_CH = 5;                                     // row pieces per thread; NP <= 320 is all the LDS admits (api.hip make_dims)
-    f32x4 lx[LNB_CH], lr[LNB_CH];                                 // (dead in the other instances)
-    float lmean = 0.f, lrstd = 0.f;
-    if (EPI == EPI_LNBWD) {
-        const int row = tid / MMT_RTPR, j = tid % MMT_RTPR, m = m0 + row;
-        if (m < M) { lmean = p.st[2 * (size_t)m]; lrstd = p.st[2 * (size_t)m + 1]; }
-#pragma unroll
-        for (int i = 0; i < LNB_CH; ++i) {
-            const int c = j * 4 + i * 4 * MMT_RTPR;
-            lx[i] = f32x4{0.f, 0.f, 0.f, 0.f}; lr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (m < M && c < p.d_real) {
-                lx[i] = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + c);
-                if (p.dres) lr[i] = *reinterpret_cast<const f32x4*>(p.dres + (size_t)m * p.lddres + c);
-            }
-        }
-    }
 
     // ------------------------------------------------------------------ 1. A tile -> LDS (bf16)
     if (ASRC == ASRC_A2) {
@@ -559,37 +540,37 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     }
 
     // ------------------------------------------------------------------ LayerNorm backward epilogue
+    // Its operands (x, LayerNorm gain, residual gradient) are loaded where they are used, one dependent round trip after the other.
+    // Fetching them early (inside the epilogue in round 1, before the k-loop in round 2: -1.5 % of the configs[3] step) is the
+    // variant that was NOT bit-reproducible while a second process shared the GPU (reproducibility); cause unknown, so
+    // the plain form stays.
     if (EPI == EPI_LNBWD) {
         __syncthreads();
         const int d = p.d_real;
         const int row = tid / TPR, j = tid % TPR, m = m0 + row;
         float* cr = Fs + row * ldf;          // dxn = grad wrt LayerNorm output (fp32)
         float* gr = Gs + row * (NP + 4);
-        const float mean = lmean, rstd = lrstd;
+        float mean = 0.f, rstd = 0.f;
+        if (m < M) { mean = p.st[2 * (size_t)m]; rstd = p.st[2 * (size_t)m + 1]; }
         {
         float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < LNB_CH; ++i) {
-            const int c = j * 4 + i * 4 * TPR;
-            if (c >= NP) break;
+        for (int c = j * 4; c < NP; c += 4 * TPR) {
             f32x4 g = {0.f, 0.f, 0.f, 0.f}, xh = {0.f, 0.f, 0.f, 0.f};
             if (m < M && c < d) {
                 f32x4 dy = *reinterpret_cast<const f32x4*>(cr + c);
-                const f32x4 xv = lx[i];
+                f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + c);
                 f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_a + c);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    xh[e] = (xv[e] - mean) * rstd;
-                    g[e] = dy[e] * a[e];
-                    s1 += g[e];
-                    s2 += g[e] * xh[e];
+                for (int i = 0; i < 4; ++i) {
+                    xh[i] = (xv[i] - mean) * rstd;
+                    g[i] = dy[i] * a[i];
+                    s1 += g[i];
+                    s2 += g[i] * xh[i];
                 }
                 f32x4 gx;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) gx[e] = dy[e] * xh[e];
+                for (int i = 0; i < 4; ++i) gx[i] = dy[i] * xh[i];
                 *reinterpret_cast<f32x4*>(gr + c) = gx;
-                lx[i] = xh;                              // second pass needs x-hat and g = dy * a, not x and dy
-                lr[i] += g * rstd;                       // dres + rstd * g
             } else {
                 *reinterpret_cast<f32x4*>(cr + c) = g;
                 *reinterpret_cast<f32x4*>(gr + c) = g;
@@ -600,13 +581,18 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         if (TPR == 16) { s1 += __shfl_xor(s1, 8); s2 += __shfl_xor(s2, 8); }
         if (m < M) {
             const float sigma = 1.0f / rstd - p.eps;
-            const float k1 = rstd * (s1 / (float)d), k2 = s2 / ((float)(d - 1) * sigma);
+            const float k1 = s1 / (float)d, k2 = s2 / ((float)(d - 1) * sigma);
+            for (int c = j * 4; c < d; c += 4 * TPR) {
+                f32x4 dy = *reinterpret_cast<const f32x4*>(cr + c);
+                f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + c);
+                f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_a + c);
+                f32x4 o;
 #pragma unroll
-            for (int i = 0; i < LNB_CH; ++i) {
-                const int c = j * 4 + i * 4 * TPR;
-                if (c >= d) break;
-                // dx = rstd * (dy a - s1/d) - k2 x-hat (+ residual gradient)
-                const f32x4 o = lr[i] - k1 - lx[i] * k2;
+                for (int i = 0; i < 4; ++i) {
+                    const float xh = (xv[i] - mean) * rstd;
+                    o[i] = rstd * (dy[i] * a[i] - k1) - k2 * xh;
+                }
+                if (p.dres) { f32x4 r = *reinterpret_cast<const f32x4*>(p.dres + (size_t)m * p.lddres + c); o += r; }
                 *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + c) = o;
                 if (KEEP & KEEP_X) *reinterpret_cast<f32x4*>(Xs + row * sm.ldx + c) = o;
             }
