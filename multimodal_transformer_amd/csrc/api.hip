@@ -146,9 +146,16 @@ static int make_dims(EncDims& D, int B, int T, int d, int h, int f, int N) {
     return MMT_OK;
 }
 
+// Which attention backward runs for this shape: the one-kernel form reads every operand in the R layout only; the two-kernel form
+// also needs the T (transposed) fragment layouts of Q, K and dO, which are allocated and written only then.
+static bool use_fused_bwd(const EncDims& D) {
+    static const bool allowed = getenv("MMT_NO_FUSED_ATTN_BWD") == nullptr;
+    return allowed && attn_bwd_fused_ok(D.L.DKP, D.nt);
+}
+
 struct LayerWs {
     float *xout, *x1, *stats1, *stats2, *lse;
-    bf16 *xn1, *xn2, *QR, *KR, *VR, *QT, *KT, *VT, *ctx, *hid;      // xn1, xn2, ctx, hid: row-major [MP][pad], operands of wgrad
+    bf16 *xn1, *xn2, *QR, *KR, *VR, *QT, *KT, *ctx, *hid;      // xn1, xn2, ctx, hid: row-major [MP][pad], operands of wgrad
     // backward operands of the weight-gradient GEMMs (row-major bf16 [MP][pad]), kept per layer so ONE batched launch forms every layer's dW
     bf16 *dx2, *dh, *dx1, *dqkv;
     float *lnpart1, *lnpart2;
@@ -180,8 +187,8 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
         w.xn1 = c.take<bf16>(MP * L.DP); w.xn2 = c.take<bf16>(MP * L.DP);          // MP rows: rows >= M stay zero for wgrad
         w.QR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); w.KR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP));
         w.VR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP));
-        w.QT = c.take<bf16>(BH * fragT_elems(D.Tp, L.DKP)); w.KT = c.take<bf16>(BH * fragT_elems(D.Tp, L.DKP));
-        w.VT = c.take<bf16>(BH * fragT_elems(D.Tp, L.DKP));
+        const size_t nT = use_fused_bwd(D) ? 0 : BH * fragT_elems(D.Tp, L.DKP);       // no T layouts for the one-kernel backward
+        w.QT = nT ? c.take<bf16>(nT) : nullptr; w.KT = nT ? c.take<bf16>(nT) : nullptr;
         w.ctx = c.take<bf16>(MP * L.HDP); w.hid = c.take<bf16>(MP * L.FP);
         w.dx2 = c.take<bf16>(MP * L.DP); w.dh = c.take<bf16>(MP * L.FP);
         w.dx1 = c.take<bf16>(MP * L.DP); w.dqkv = c.take<bf16>(MP * L.NQ);
@@ -198,7 +205,8 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
     W.dxa = c.take<float>(M * D.d); W.dxb = c.take<float>(M * D.d);
     W.delta = c.take<float>(BH * D.Tp);
     W.lnpartf = c.take<float>((size_t)D.G * 2 * L.DP);
-    W.dOR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); W.dOT = c.take<bf16>(BH * fragT_elems(D.Tp, L.DKP));
+    W.dOR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP));
+    W.dOT = use_fused_bwd(D) ? nullptr : c.take<bf16>(BH * fragT_elems(D.Tp, L.DKP));
     const size_t S = D.nsplit;
     {   // one slab set per layer, identical sizes: layer l's set lives at + l * slab_stride floats
         const size_t before = c.off;
@@ -281,20 +289,20 @@ static int launch_mask_gen(uint16_t* mq, uint16_t* mk, const EncDims& D, int nla
 }
 
 // `drop`: the layer's attention dropout (thr16 == 0: off); maskQ: its lane words, written by launch_mask_gen
-static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* VT, bf16* ctx, float* lse,
+static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* VR, bf16* ctx, float* lse,
                            const EncDims& D, hipStream_t st, DropCfg drop = no_drop(), const uint16_t* maskQ = nullptr) {
     dim3 grid(attn_grid((D.nt + 3) / 4, D.B * D.h));
     if (drop.thr16 && !maskQ) return fail(MMT_EINVAL, "attention dropout without a mask buffer");
     ProfScope prof(S_ATTN_FWD, st);
 #define MMT_FWD(dkp, dr) for (int fb = 0; fb < (dkp + 31) / 32; ++fb) \
-        hipLaunchKernelGGL((attn_fwd_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, lse, \
+        hipLaunchKernelGGL((attn_fwd_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VR, ctx, lse, \
                            D.h, D.T, D.nt, D.B * D.h, D.L.HDP, maskQ, drop.scale, fb)
 #ifdef MMT_ABLATIONS
     static const int abl = getenv("MMT_ABL") ? atoi(getenv("MMT_ABL")) : 0;
-#define MMT_FWD_A(a) hipLaunchKernelGGL((attn_fwd_kernel<16, true, a>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VT, ctx, lse, \
+#define MMT_FWD_A(a) hipLaunchKernelGGL((attn_fwd_kernel<16, true, a>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VR, ctx, lse, \
                                         D.h, D.T, D.nt, D.B * D.h, D.L.HDP, maskQ, drop.scale, 0)
     if (abl && DKP == 16 && drop.thr16) {
-        switch (abl) { case 1: MMT_FWD_A(1); break; case 2: MMT_FWD_A(2); break; case 3: MMT_FWD_A(3); break; case 4: MMT_FWD_A(4); break;
+        switch (abl) { case 1: MMT_FWD_A(1); break; case 2: MMT_FWD_A(2); break; case 3: MMT_FWD_A(3); break;
                        case 5: MMT_FWD_A(5); break; default: MMT_FWD_A(6); }
         LAUNCH_CHECK("attn_fwd_kernel"); return MMT_OK;
     }
@@ -315,8 +323,7 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
     dim3 grid(attn_grid((D.nt + 3) / 4, D.B * D.h));
     const float scale = 1.0f / sqrtf((float)D.L.dk);
     if (drop.thr16 && (!maskQ || !maskK)) return fail(MMT_EINVAL, "attention dropout without mask buffers");
-    static const bool fused = getenv("MMT_NO_FUSED_ATTN_BWD") == nullptr;
-    if (fused && attn_bwd_fused_ok(DKP, D.nt)) {        // one evaluation of P and dS per score: attn_bwd_fused.h
+    if (use_fused_bwd(D)) {                             // one evaluation of P and dS per score: attn_bwd_fused.h
         static bool configured = false;
         if (!configured) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -325,14 +332,14 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
         }
         ProfScope prof(S_ATTN_BWD_FUSED, st);
 #define MMT_FUSED(dr) hipLaunchKernelGGL((attn_bwd_fused16_kernel<dr>), dim3(D.B * D.h), dim3(MMT_FUSED_THREADS), MMT_FUSED_LDS_BYTES, st, \
-                                          QR, QT, KR, KT_, VR, dOR, dOT, lse, delta, rowmask, scale, dqkv, D.L.NQ, D.h, D.T, D.nt, maskK, drop.scale)
+                                          QR, KR, VR, dOR, lse, delta, rowmask, scale, dqkv, D.L.NQ, D.h, D.T, D.nt, maskK, drop.scale)
 #ifdef MMT_ABLATIONS
         static const bool stamp = getenv("MMT_ABL") && atoi(getenv("MMT_ABL")) == 7;
         if (stamp && drop.thr16) {
             static bool c2 = false;
             if (!c2) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); c2 = true; }
             hipLaunchKernelGGL((attn_bwd_fused16_kernel<true, true>), dim3(D.B * D.h), dim3(MMT_FUSED_THREADS), MMT_FUSED_LDS_BYTES, st,
-                               QR, QT, KR, KT_, VR, dOR, dOT, lse, delta, rowmask, scale, dqkv, D.L.NQ, D.h, D.T, D.nt, maskK, drop.scale);
+                               QR, KR, VR, dOR, lse, delta, rowmask, scale, dqkv, D.L.NQ, D.h, D.T, D.nt, maskK, drop.scale);
             LAUNCH_CHECK("attn_bwd_fused16_kernel");
             return MMT_OK;
         }
@@ -431,7 +438,7 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
             p.ln_a = Pl + L.oln(0); p.ln_b = Pl + L.oln(1); p.eps = eps; p.stats = wl.stats1;
             p.W = W.wprep + (size_t)ll * L.pstride() + L.pWqkv(); p.bias = W.bprep + (size_t)ll * L.qstride() + L.qbqkv();
             p.fragR[0] = wl.QR; p.fragR[1] = wl.KR; p.fragR[2] = wl.VR;
-            p.fragT[0] = wl.QT; p.fragT[1] = wl.KT; p.fragT[2] = wl.VT;
+            p.fragT[0] = wl.QT; p.fragT[1] = wl.KT; p.fragT[2] = nullptr;      // V is only ever read window-major (attn_fwd: transposing LDS reads)
             p.T = T; p.Tp = D.Tp; p.h = h; p.DKP = L.DKP; p.nwhich = 3;
             p.rowmask = mask; p.qscale = LOG2E / sqrtf((float)L.dk); p.scale_first = 1;
             return p;
@@ -441,7 +448,7 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
             if ((rc = launch_rowgemm<EPI_FRAG, true>(p, st, S_LN1_QKV))) return rc;
         }
         // dropout streams of layer l: 4l+0 attention probabilities (:33), 4l+1 / 4l+3 sublayer outputs (:104), 4l+2 FFN hidden (:20)
-        if ((rc = launch_attn_fwd(L.DKP, w.QR, w.KR, w.VT, w.ctx, w.lse, D, st, make_drop(dropout_p, seed, 4 * l + 0), w.maskQ))) return rc;
+        if ((rc = launch_attn_fwd(L.DKP, w.QR, w.KR, w.VR, w.ctx, w.lse, D, st, make_drop(dropout_p, seed, 4 * l + 0), w.maskQ))) return rc;
         {   // out-proj + residual -> LN2 + FFN1 + ReLU -> FFN2 + residual, one kernel, x1 and hid stay in LDS
             RowChain3 ch; memset(&ch, 0, sizeof(ch));
             {   RowGemmParams& p = ch.a; p = rg_zero();
@@ -666,7 +673,7 @@ __global__ void pack_frag_kernel(const float* __restrict__ src, bf16* __restrict
         for (int e = 0; e < dk; ++e) {
             const bf16 v = (bf16)(src[(size_t)m * d + head * dk + e] * sc);
             fr[bh * fragR_elems(Tp, DKP) + fragR_index(t, e, DKP)] = v;
-            ft[bh * fragT_elems(Tp, DKP) + fragT_index(t, e, Tp)] = v;
+            if (ft) ft[bh * fragT_elems(Tp, DKP) + fragT_index(t, e, Tp)] = v;
             if (delta) part += (float)v * (float)ctx[(size_t)m * ldctx + head * DKP + e];
         }
         if (delta) delta[bh * Tp + t] = -part;       // stored negated, like the fused path
@@ -682,14 +689,15 @@ __global__ void unpad_heads_kernel(const bf16* __restrict__ src, int ld, int col
     }
 }
 
-struct SdpaWs { bf16 *QR, *QT, *KR, *KT, *VR, *VT, *dOR, *dOT, *ctx, *dqkv; float *lse, *delta; uint16_t *maskQ, *maskK; size_t bytes; };
+struct SdpaWs { bf16 *QR, *QT, *KR, *KT, *VR, *dOR, *dOT, *ctx, *dqkv; float *lse, *delta; uint16_t *maskQ, *maskK; size_t bytes; };
 static void carve_sdpa(SdpaWs& W, const EncDims& D, void* base) {
     Carver c(base);
     const LayerLayout& L = D.L;
     const size_t BH = (size_t)D.B * D.h, M = D.M;
     bf16** r[] = {&W.QR, &W.KR, &W.VR, &W.dOR};
-    bf16** t[] = {&W.QT, &W.KT, &W.VT, &W.dOT};
-    for (int i = 0; i < 4; ++i) { *r[i] = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); *t[i] = c.take<bf16>(BH * fragT_elems(D.Tp, L.DKP)); }
+    bf16** t[] = {&W.QT, &W.KT, &W.dOT};
+    for (int i = 0; i < 4; ++i) *r[i] = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP));
+    for (int i = 0; i < 3; ++i) *t[i] = use_fused_bwd(D) ? nullptr : c.take<bf16>(BH * fragT_elems(D.Tp, L.DKP));
     W.ctx = c.take<bf16>(M * L.HDP);
     W.dqkv = c.take<bf16>(M * L.NQ);
     W.lse = c.take<float>(BH * D.Tp); W.delta = c.take<float>(BH * D.Tp);
@@ -726,10 +734,10 @@ extern "C" int mmt_sdpa_forward(const float* q, const float* k, const float* v, 
     const float qs = LOG2E / sqrtf((float)L.dk);
     hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, q, W.QR, W.QT, mask, qs, 1, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
     hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, k, W.KR, W.KT, nullptr, 1.f, 0, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
-    hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, v, W.VR, W.VT, nullptr, 1.f, 0, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, v, W.VR, nullptr, nullptr, 1.f, 0, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
     LAUNCH_CHECK("pack_frag_kernel");
     if (dropout_p > 0.f && (rc = launch_mask_gen(W.maskQ, W.maskK, D, 1, dropout_p, seed, st))) return rc;
-    if ((rc = launch_attn_fwd(L.DKP, W.QR, W.KR, W.VT, W.ctx, W.lse, D, st, make_drop(dropout_p, seed, 0), W.maskQ))) return rc;
+    if ((rc = launch_attn_fwd(L.DKP, W.QR, W.KR, W.VR, W.ctx, W.lse, D, st, make_drop(dropout_p, seed, 0), W.maskQ))) return rc;
     hipLaunchKernelGGL(unpad_heads_kernel, dim3(grid_for((size_t)D.M * d)), dim3(256), 0, st, W.ctx, L.HDP, 0, ctx, D.M, h, L.dk, L.DKP, d);
     LAUNCH_CHECK("unpad_heads_kernel");
     return MMT_OK;

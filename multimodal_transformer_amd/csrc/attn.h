@@ -29,18 +29,22 @@
 template <int NSEG, int MAXL = 3>
 struct TileStager {
     // segment i: `pieces[i]` 16-byte pieces per tile, read from base[i] + tile * stride[i] (bf16 elements); thread t moves pieces
-    // t, t + 256, ... (MAXL = ceil(total pieces / 256) of them)
-    const bf16* src[MAXL]; int stride[MAXL]; bool on[MAXL]; int tid;
+    // t, t + 256, ... (MAXL = ceil(total pieces / 256) of them).  In LDS segment i starts at piece lds0[i] and leaves pad[i] pieces
+    // free after every 32 (an R-layout tile that is read with transposing reads keeps its 8-feature groups 576 bytes apart:
+    // the four groups a 32-lane half touches then fall into the four quarters of the 64 banks).
+    const bf16* src[MAXL]; int stride[MAXL]; bool on[MAXL]; int dst[MAXL];
     bf16x8 reg[MAXL];
-    __device__ __forceinline__ void init(const bf16* const* base, const int* pieces, const int* strides, int tid_) {
-        tid = tid_;
+    __device__ __forceinline__ void init(const bf16* const* base, const int* pieces, const int* strides, const int* lds0, const int* pad, int tid) {
 #pragma unroll
         for (int l = 0; l < MAXL; ++l) {
             const int p = tid + MMT_THREADS * l;
-            int acc = 0; on[l] = false; src[l] = base[0]; stride[l] = 0;
+            int acc = 0; on[l] = false; src[l] = base[0]; stride[l] = 0; dst[l] = 0;
 #pragma unroll
             for (int sg = 0; sg < NSEG; ++sg) {
-                if (!on[l] && p >= acc && p < acc + pieces[sg]) { on[l] = true; src[l] = base[sg] + (size_t)(p - acc) * 8; stride[l] = strides[sg]; }
+                if (!on[l] && p >= acc && p < acc + pieces[sg]) {
+                    on[l] = true; src[l] = base[sg] + (size_t)(p - acc) * 8; stride[l] = strides[sg];
+                    dst[l] = (lds0[sg] + (p - acc) + ((p - acc) >> 5) * pad[sg]) * 8;
+                }
                 acc += pieces[sg];
             }
         }
@@ -51,9 +55,10 @@ struct TileStager {
     }
     __device__ __forceinline__ void store(bf16* lds) const {
 #pragma unroll
-        for (int l = 0; l < MAXL; ++l) if (on[l]) *reinterpret_cast<bf16x8*>(lds + (tid + MMT_THREADS * l) * 8) = reg[l];
+        for (int l = 0; l < MAXL; ++l) if (on[l]) *reinterpret_cast<bf16x8*>(lds + dst[l]) = reg[l];
     }
 };
+#define MMT_TR_OCT 36        // pieces between the 8-feature groups of a padded R tile in LDS (32 windows + 4 free)
 
 // all 16 registers = x in eight 64-bit moves (hipcc writes a splat as sixteen v_mov_b32).  The trailing s_nop covers the two
 // wait states an MFMA needs after a VALU write of its SrcC: the hazard recognizer does not see through asm statements.
@@ -108,7 +113,7 @@ __device__ __forceinline__ AttnBlock attn_block(int nx, int nbh) {
 __host__ inline int attn_grid(int nx, int nbh) { return nx * 8 * ((nbh + 7) / 8); }
 
 // ABL != 0: timing-only ablations (results are WRONG; tools/attn_ablate.py): 1 no running max / rescale, 2 no exp,
-// 3 no PV product, 4 operands straight from global memory (no LDS staging, no barrier), 5 no row sums,
+// 3 no PV product, 5 no row sums,
 // 6 correct results + s_memtime stamps at seven points of the tile body, summed per wave into g_attn_stamps (diagnostic build)
 #ifdef MMT_ABLATIONS
 __device__ unsigned long long* g_attn_stamps = nullptr;        // [wave id][16]: 0..5, 7 segment sums; 6 wave lifetime; 8 / 9 entry / exit (100 MHz)
@@ -120,7 +125,7 @@ __device__ unsigned long long* g_attn_stamps = nullptr;        // [wave id][16]:
 #endif
 template <int DKP, bool DROP, int ABL = 0>
 __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
-        const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vt,
+        const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vr,
         bf16* __restrict__ ctx, float* __restrict__ lse,
         int h, int T, int nt, int nbh, int ldc, const uint16_t* __restrict__ maskQ, float drop_scale, int fb) {
     constexpr int KS = DKP / 16;
@@ -130,8 +135,12 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
     unsigned long long st_entry = 0, st_entry_rt = 0;
     if (ABL == 6) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_entry), "=s"(st_entry_rt) :: "memory");
 #endif
-    constexpr int PK = DKP * 4, PV = 128;              // 16-byte pieces of one K (R layout) / V (T layout) tile
-    __shared__ __attribute__((aligned(16))) bf16 stage[2][(PK + PV) * 8];
+    // 16-byte pieces per tile: K (R layout, all DKP features) and the 32-feature block `fb` of V — ALSO in the R layout, as the QKV
+    // epilogue wrote it: the PV product contracts over keys, its A fragment (8 keys of one feature per lane) comes out of LDS
+    // through transposing reads (tr_frag2), so no transposed copy of V exists in memory
+    constexpr int PK = DKP * 4, PV = DKB * 4, PVL = (DKB / 8) * MMT_TR_OCT;
+    __shared__ __attribute__((aligned(16))) bf16 stage[2][(PK + PVL) * 8];
+    __shared__ __attribute__((aligned(16))) bf16 zeros[256];          // what the lanes of the padding feature rows (>= d_k) read
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const AttnBlock ab = attn_block((nt + 3) >> 2, nbh);
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
     const int Tp = nt * 32;
     const bf16* Qb = Qr + (size_t)bh * fragR_elems(Tp, DKP);
     const bf16* Kb = Kr + (size_t)bh * fragR_elems(Tp, DKP);
-    const bf16* Vb = Vt + (size_t)bh * fragT_elems(Tp, DKP) + (size_t)fb * Tp * 32;
+    const bf16* Vb = Vr + (size_t)bh * fragR_elems(Tp, DKP) + (size_t)fb * 4 * 256;      // feature group 4 fb of tile 0
     // dropout: this lane's 16-bit words of the wave's row of mask blocks (attn_mask.h, LQ layout), one per key tile, fetched a tile ahead
     const uint16_t* mrow = maskQ + ((size_t)bh * nt + qtc) * nt * 64 + lane;
     uint32_t mw = DROP ? mrow[0] : 0u;
@@ -151,10 +160,17 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
     TileStager<2, (PK + PV + MMT_THREADS - 1) / MMT_THREADS> stg;
     {
         const bf16* base[2] = {Kb, Vb};
-        const int pieces[2] = {PK, PV}, strides[2] = {32 * DKP, 1024};
-        stg.init(base, pieces, strides, threadIdx.x);
+        const int pieces[2] = {PK, PV}, strides[2] = {32 * DKP, 32 * DKP}, lds0[2] = {0, PK}, pad[2] = {0, MMT_TR_OCT - 32};
+        stg.init(base, pieces, strides, lds0, pad, threadIdx.x);
     }
     stg.load(0);
+    zeros[threadIdx.x] = (bf16)0.f;
+    // transposing-read role of this lane in the V tile: its feature row r = 16 g1 + (lane & 15) is delivered by the hardware; the
+    // address it SUPPLIES is that of window q = (lane >> 2) & 3 of a 4-window block, features 16 g1 + 4 pp .. + 3, pp = lane & 3.
+    // Key order of the fragment = row order of the P^T accumulator: slot j <-> key 16 s2 + 8 (j >> 2) + 4 hh + (j & 3).
+    const int g1 = (lane >> 4) & 1, tq = (lane >> 2) & 3, tpp = lane & 3;
+    const int voff = ((2 * g1 + (tpp >> 1)) * MMT_TR_OCT + 4 * hh + tq) * 8 + 4 * (tpp & 1);
+    const bool vpad = DKB < 32 && g1;                   // feature rows >= 16 at d_k = 16: zeros (or the ones row, below)
     bf16x8 qf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
@@ -185,9 +201,9 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
         progress_prio(kt, nt);
         const uint32_t tw = mw;                          // this tile's keep bits
         if (DROP && !TAIL) mw = mrow[(size_t)(kt + 1) * 64];
-        if (!TAIL && ABL != 4) stg.load(kt + 1);        // next tile in flight behind this tile's arithmetic
-        const bf16* sk = (ABL == 4) ? Kb + (size_t)kt * 32 * DKP : stage[kt & 1];
-        const bf16* sv = (ABL == 4) ? Vb + (size_t)kt * 1024 : sk + PK * 8;
+        if (!TAIL) stg.load(kt + 1);                    // next tile in flight behind this tile's arithmetic
+        const bf16* sk = stage[kt & 1];
+        const bf16* sv = vpad ? zeros : sk + PK * 8 + voff;
         f32x16 s;
         fill16(s, (kt == 0) ? 0.f : -mrun);
 #pragma unroll
@@ -232,8 +248,8 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
         ATT_STAMP(2);                                   // mask wait + selects
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 va = *reinterpret_cast<const bf16x8*>(sv + ((s2 * 2 + hh) * 32 + r) * 8);
-            if (ONES && r == DKP) va = ones;           // V^T rows >= DKP are zero in memory; row DKP becomes the ones row
+            bf16x8 va = tr_frag2(sv + 128 * s2, sv + 128 * s2 + 64);       // keys 16 s2 + 4 hh + {0..3}, then + 8
+            if (ONES && r == DKP) va = ones;           // V^T rows >= DKP read zeros; row DKP becomes the ones row
             if (ABL == 3) {
                 const bf16x8 pk = pack8(s, s2);
 #pragma unroll
@@ -242,12 +258,10 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
             o = mfma32(va, pack8(s, s2), o);
         }
         ATT_STAMP(3);                                   // V fragment reads, packs, PV issue
-        if (ABL != 4) {
         if (!TAIL) stg.store(stage[(kt + 1) & 1]);
         ATT_STAMP(4);                                   // wait for the staged tile's global loads + LDS writes
         __syncthreads();        // stage[(kt+1)&1] was last read at tile kt-1, i.e. before the previous barrier
         ATT_STAMP(5);                                   // barrier
-        }
     };
     for (int kt = 0; kt < nt - 1; ++kt) body(std::false_type{}, kt);
     body(std::true_type{}, nt - 1);
@@ -325,7 +339,9 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
         const bf16* base[6] = {Qr + offR, dOr + offR, Qt + offT, dOt + offT,
                                reinterpret_cast<const bf16*>(lse + (size_t)bh * Tp), reinterpret_cast<const bf16*>(delta + (size_t)bh * Tp)};
         const int pieces[6] = {PR, PR, PT, PT, PC, PC}, strides[6] = {32 * DKP, 32 * DKP, 1024, 1024, 64, 64};
-        stg.init(base, pieces, strides, threadIdx.x);
+        int lds0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 1; i < (int)(sizeof(pieces) / sizeof(pieces[0])); ++i) lds0[i] = lds0[i - 1] + pieces[i - 1];
+        stg.init(base, pieces, strides, lds0, pad, threadIdx.x);
     }
     stg.load(0);
     bf16x8 kfr[KS], vfr[KS];
@@ -475,7 +491,9 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
     {
         const bf16* base[3] = {Kr + offR, Vr + offR, Kt + offT};
         const int pieces[3] = {PR, PR, PT}, strides[3] = {32 * DKP, 32 * DKP, 1024};
-        stg.init(base, pieces, strides, threadIdx.x);
+        int lds0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 1; i < (int)(sizeof(pieces) / sizeof(pieces[0])); ++i) lds0[i] = lds0[i - 1] + pieces[i - 1];
+        stg.init(base, pieces, strides, lds0, pad, threadIdx.x);
     }
     stg.load(0);
     bf16x8 qf[KS], dof[KS];

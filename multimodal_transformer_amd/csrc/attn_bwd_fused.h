@@ -7,14 +7,17 @@
 // (attn_bwd_dkv_kernel's d_k = 16 trick); all waves sweep the query tiles together, sharing the staged Q / dO / L / delta tile like
 // the 4-wave kernels do.  Per query tile each wave also forms its 32-key share of dQ^T = K^T dS^T:
 //   * dS sits in the accumulator layout with the key on the lane; the dQ product contracts over keys, so dS goes through a
-//     wave-private LDS patch [32 queries][32 keys] bf16 (16 ds_write_b16 + 2 ds_read_b128 per lane) to become a B operand, the key
-//     columns permuted to the order the T-layout K^T tile presents them;
+//     wave-private LDS patch [32 queries][32 keys] bf16 (16 ds_write_b16 + 2 ds_read_b128 per lane) to become a B operand;
+//   * every operand exists in memory in ONE layout, the R fragment layout (window-major).  The products that contract over windows
+//     (dV^T += dO^T P, dK^T += Q'^T dS over the queries, dQ^T = K^T dS^T over the keys) take their A fragments out of the staged
+//     tiles with transposing LDS reads (common.h tr_frag2); round 1/2 staged a second, transposed copy of Q and dO (2 KB of the
+//     3.2 KB per tile, half of it zero padding) and kept a transposed copy of the own K tile;
 //   * the fp32 partial (8 registers for d_k <= 16) overwrites the patch, and after the tile's barrier all 16 waves sum the 16
 //     partials in a fixed order (bit-reproducible, no atomics), apply 1/sqrt(d_k) and the query-row mask and store both layouts of
 //     dQ — each wave 32 outputs per layout, coalesced.  Patch/partial regions are double-buffered by tile parity, so one barrier
 //     per tile orders everything;
 //   * the score products of tile t+1 are issued before the barrier that closes tile t (three-deep staging ring), see "Pipeline".
-// Registers: 16 waves per CU means 128 VGPRs per wave; the kernel is written to fit (the own tile's K, V and K^T fragments live in
+// Registers: 16 waves per CU means 128 VGPRs per wave; the kernel is written to fit (the own tile's K and V fragments live in
 // LDS instead of registers, the staging ring needs one 16-byte piece per thread).
 //
 // Reference semantics: transformer/MFT/multiTransformer.py:22-34 (scaled dot-product attention) under autograd.
@@ -26,8 +29,12 @@
 #define MMT_FUSED_PATCH_LD 40                               // bf16 per patch row: 32 keys + 8 pad (80-byte rows: conflict-free b128 reads)
 #define MMT_FUSED_PART_LD 68                                // floats per partial register row: 64 lanes + 4 pad
 #define MMT_FUSED_REGION_BYTES 2560                         // max(32 * 40 * 2, 8 * 68 * 4)
-#define MMT_FUSED_STAGE_PIECES 400                          // 2 * 64 (R tiles) + 2 * 128 (T tiles) + 2 * 8 (row constants)
-#define MMT_FUSED_LDS_BYTES (3 * MMT_FUSED_STAGE_PIECES * 16 + MMT_FUSED_NW * 3072 + MMT_FUSED_NW * 2 * MMT_FUSED_REGION_BYTES)     // 150,272 of 163,840
+#define MMT_FUSED_RT_PIECES (2 * MMT_TR_OCT)                // an R tile of d_k = 16 in LDS: two 8-feature groups, 576 bytes apart (attn.h TileStager)
+#define MMT_FUSED_STAGE_PIECES (2 * MMT_FUSED_RT_PIECES + 16)        // LDS pieces per staged query tile: Q, dO, 2 * 8 pieces of row constants
+#define MMT_FUSED_STAGE_LOADS 144                           // 16-byte pieces fetched per query tile: 2 * 64 + 2 * 8
+#define MMT_FUSED_ZERO_BYTES 512
+#define MMT_FUSED_LDS_BYTES (3 * MMT_FUSED_STAGE_PIECES * 16 + MMT_FUSED_ZERO_BYTES + MMT_FUSED_NW * 2 * MMT_FUSED_RT_PIECES * 16 \
+                             + MMT_FUSED_NW * 2 * MMT_FUSED_REGION_BYTES)     // 126,976 of 163,840
 
 __host__ inline bool attn_bwd_fused_ok(int DKP, int nt) { return DKP == 16 && nt > 8 && nt <= MMT_FUSED_NW; }
 
@@ -41,62 +48,63 @@ __host__ inline bool attn_bwd_fused_ok(int DKP, int nt) { return DKP == 16 && nt
 #endif
 template <bool DROP, bool STAMP = false>
 __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
-        const bf16* __restrict__ Qr, const bf16* __restrict__ Qt, const bf16* __restrict__ Kr, const bf16* __restrict__ Kt,
-        const bf16* __restrict__ Vr, const bf16* __restrict__ dOr, const bf16* __restrict__ dOt,
+        const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vr, const bf16* __restrict__ dOr,
         const float* __restrict__ lse, const float* __restrict__ delta, const float* __restrict__ rowmask, float scale,
         bf16* __restrict__ dqkv, int lddkv,     // row-major [M][lddkv]: dQ at column 0, dK at HD, dV at 2*HD
         int h, int T, int nt, const uint16_t* __restrict__ maskK, float drop_scale) {
-    constexpr int DKP = 16, PR = 64, PT = 128, PC = 8, TOTAL = MMT_FUSED_STAGE_PIECES;
+    constexpr int DKP = 16, PR = 64, RT = MMT_FUSED_RT_PIECES, PC = 8, TOTAL = MMT_FUSED_STAGE_PIECES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* const stage0 = reinterpret_cast<bf16*>(smem);                                 // [3][TOTAL * 8] bf16: ring of query tiles
-    char* const ktl0 = smem + 3 * TOTAL * 16;                                           // [NW][1024]: own K^T tile, its 16 real rows
-    char* const kvl0 = ktl0 + MMT_FUSED_NW * 1024;                                      // [NW][2][1024]: own K and V tiles (R layout)
-    char* const reg0 = kvl0 + MMT_FUSED_NW * 2048;                                      // [NW][2][REGION]
+    const bf16* const zeros = reinterpret_cast<const bf16*>(smem + 3 * TOTAL * 16);     // what the padding feature rows of an A fragment read
+    char* const kvl0 = smem + 3 * TOTAL * 16 + MMT_FUSED_ZERO_BYTES;                    // [NW][2][RT * 16]: own K and V tiles (R layout, padded groups)
+    char* const reg0 = kvl0 + MMT_FUSED_NW * 2 * RT * 16;                               // [NW][2][REGION]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int kt = wave;
     const bool live = kt < nt;                          // idle waves stage, synchronise and take their share of the dQ reduction
     const int bh = blockIdx.x, b = bh / h, head = bh - b * h;
     const int Tp = nt * 32, HD = h * DKP;
-    const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp, DKP);
+    const size_t offR = (size_t)bh * fragR_elems(Tp, DKP);
     // dropout: this lane's words of the wave's row of mask blocks (attn_mask.h, LK layout: key on the lane), one per query tile, a tile ahead
     const uint16_t* mrow = maskK + ((size_t)bh * nt + (live ? kt : 0)) * nt * 64 + lane;
     uint32_t mw = DROP ? mrow[0] : 0u;
     const uint32_t scale_bits = __builtin_bit_cast(uint32_t, drop_scale);
 
-    // ---- staging ring: thread p < 400 moves piece p of every tile (segments: Q R, dO R, Q T, dO T, L, delta)
-    const bf16* ssrc; int sstride; const bool son = tid < TOTAL;
+    // ---- staging ring: thread p < 144 moves piece p of every tile (segments: Q, dO in the R layout, L, delta)
+    const bf16* ssrc; int sstride, sdst; const bool son = tid < MMT_FUSED_STAGE_LOADS;
     {
-        const bf16* base[6] = {Qr + offR, dOr + offR, Qt + offT, dOt + offT,
+        const bf16* base[4] = {Qr + offR, dOr + offR,
                                reinterpret_cast<const bf16*>(lse + (size_t)bh * Tp), reinterpret_cast<const bf16*>(delta + (size_t)bh * Tp)};
-        const int pieces[6] = {PR, PR, PT, PT, PC, PC}, strides[6] = {32 * DKP, 32 * DKP, 1024, 1024, 64, 64};
-        int acc = 0; ssrc = base[0]; sstride = 0;
+        const int pieces[4] = {PR, PR, PC, PC}, strides[4] = {32 * DKP, 32 * DKP, 64, 64}, lds0[4] = {0, RT, 2 * RT, 2 * RT + PC};
+        int acc = 0; ssrc = base[0]; sstride = 0; sdst = 0;
 #pragma unroll
-        for (int sg = 0; sg < 6; ++sg) {
-            if (tid >= acc && tid < acc + pieces[sg]) { ssrc = base[sg] + (size_t)(tid - acc) * 8; sstride = strides[sg]; }
+        for (int sg = 0; sg < 4; ++sg) {
+            if (tid >= acc && tid < acc + pieces[sg]) {
+                const int q = tid - acc;
+                ssrc = base[sg] + (size_t)q * 8; sstride = strides[sg];
+                sdst = (lds0[sg] + q + (sg < 2 ? (q >> 5) * (MMT_TR_OCT - 32) : 0)) * 8;
+            }
             acc += pieces[sg];
         }
     }
     bf16x8 sreg;
     auto stage_load = [&](int tile) { if (son) sreg = *reinterpret_cast<const bf16x8*>(ssrc + (size_t)tile * sstride); };
     auto stage_store = [&](int buf) {
-        int to = tid;
+        int to = sdst;
         asm volatile("" : "+v"(to));
-        if (son) *reinterpret_cast<bf16x8*>(stage0 + (size_t)buf * TOTAL * 8 + to * 8) = sreg;
+        if (son) *reinterpret_cast<bf16x8*>(stage0 + (size_t)buf * TOTAL * 8 + to) = sreg;
     };
+    if (tid < MMT_FUSED_ZERO_BYTES / 4) reinterpret_cast<unsigned*>(smem + 3 * TOTAL * 16)[tid] = 0u;
     stage_load(0);
 
     // ---- per-wave constants
     char* const myreg = reg0 + wave * 2 * MMT_FUSED_REGION_BYTES;
-    char* const mykv = kvl0 + wave * 2048 + lane * 16;
+    char* const mykv = kvl0 + wave * (2 * RT * 16) + (hh * MMT_TR_OCT + r) * 16;
     {
         const int ktc = live ? kt : 0;
         const size_t off = ((size_t)(ktc * (DKP / 8) + hh) * 32 + r) * 8;
         *reinterpret_cast<bf16x8*>(mykv) = *reinterpret_cast<const bf16x8*>(Kr + offR + off);
-        *reinterpret_cast<bf16x8*>(mykv + 1024) = *reinterpret_cast<const bf16x8*>(Vr + offR + off);
-        // own K^T tile -> LDS, the A operand of the dQ product: only feature rows < 16 of each (s, hh) block are real (one piece per lane)
-        const bf16* ksrc = Kt + offT + (size_t)ktc * 1024;
-        *reinterpret_cast<bf16x8*>(ktl0 + wave * 1024 + lane * 16) = *reinterpret_cast<const bf16x8*>(ksrc + ((lane >> 4) * 32 + (lane & 15)) * 8);
+        *reinterpret_cast<bf16x8*>(mykv + RT * 16) = *reinterpret_cast<const bf16x8*>(Vr + offR + off);
         if (!live) {                                    // an idle wave's partials are zero forever
 #pragma unroll
             for (int par = 0; par < 2; ++par)
@@ -135,10 +143,10 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
     auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
     auto scores = [&](int buf) {        // row constants (4 consecutive queries per register group) are the accumulator init
         const int lo = opaque(lane), r = lo & 31, hh = lo >> 5;
-        char* const mykv = kvl0 + wave * 2048 + lo * 16;
+        char* const mykv = kvl0 + wave * (2 * RT * 16) + (hh * MMT_TR_OCT + r) * 16;
         const bf16* sq = stage0 + (size_t)buf * TOTAL * 8;
-        const bf16* sdo = sq + PR * 8;
-        const float* sl = reinterpret_cast<const float*>(sq + (2 * PR + 2 * PT) * 8);
+        const bf16* sdo = sq + RT * 8;
+        const float* sl = reinterpret_cast<const float*>(sq + 2 * RT * 8);
         const float* sd = sl + 32;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -148,9 +156,9 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
 #pragma unroll
             for (int i = 0; i < 4; ++i) { s[4 * g + i] = l4[i]; dp[4 * g + i] = d4[i]; }      // both stored negated
         }
-        const int o8 = (hh * 32 + r) * 8;
+        const int o8 = (hh * MMT_TR_OCT + r) * 8;
         s = mfma32(*reinterpret_cast<const bf16x8*>(sq + o8), *reinterpret_cast<const bf16x8*>(mykv), s);
-        dp = mfma32(*reinterpret_cast<const bf16x8*>(sdo + o8), *reinterpret_cast<const bf16x8*>(mykv + 1024), dp);
+        dp = mfma32(*reinterpret_cast<const bf16x8*>(sdo + o8), *reinterpret_cast<const bf16x8*>(mykv + RT * 16), dp);
     };
     if (live) scores(0);
     else {
@@ -198,9 +206,8 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
         if (live) {
             const uint32_t tw = mw;
             if (DROP && NEXT) mw = mrow[(size_t)(qt + 1) * 64];
-            const bf16* sqt = stage0 + (size_t)cur * TOTAL * 8 + 2 * PR * 8;
-            const bf16* sdt = sqt + PT * 8;
-            const float* sd = reinterpret_cast<const float*>(sdt + PT * 8) + 32;
+            const bf16* const sqc = stage0 + (size_t)cur * TOTAL * 8;                       // this tile's Q (then dO, L, delta)
+            const float* sd = reinterpret_cast<const float*>(sqc + 2 * RT * 8) + 32;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 float pv = fast_exp2(s[j]);
@@ -229,32 +236,37 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
                 for (int j = 0; j < 16; ++j) dp[j] *= s[j];
             }
             FB_STAMP(1);                                // exponentials, dropout, dS
-            // dV^T / dK^T, and dS into the patch on the way.  This lane's key column goes where the K^T tile's k-order wants it (bits 2
-            // and 3 of the key swapped).
-            const int lo = opaque(lane), r = lo & 31, hh = lo >> 5, rq = r ^ 16;
-            const int pcol = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);
+            // dV^T / dK^T, and dS into the patch on the way.  A fragments by transposing reads of the staged dO / Q tiles: the lane
+            // SUPPLIES the address of query tq of a 4-query block, features 4 tpp .. + 3, and receives feature (lane & 15); fragment slot j
+            // <-> query 16 s2 + 8 (j >> 2) + 4 hh + (j & 3), the row order of the P / dS accumulators.  dV^T lives in accumulator rows
+            // 0..15 (lanes r < 16 read dO, the others zeros), dK^T in rows 16..31 (lanes r >= 16 read Q, the others zeros).
+            const int lo = opaque(lane), r = lo & 31, hh = lo >> 5;
+            const int tq = (lo >> 2) & 3, tpp = lo & 3, toff = (tpp >> 1) * (MMT_TR_OCT * 8) + 4 * (tpp & 1) + tq * 8;
+            const bool up = (lo >> 4) & 1;
+            const bf16* const ado = up ? zeros : sqc + RT * 8 + toff + 32 * hh;
+            const bf16* const aq = up ? sqc + toff + 32 * hh : zeros;
             bf16* const patch = reinterpret_cast<bf16*>(region);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const int o8b = ((s2 * 2 + hh) * 32 + r) * 8;
                 const bf16x8 pds = pack8(dp, s2);
-                acc = mfma32(*reinterpret_cast<const bf16x8*>(sdt + o8b), pack8(s, s2), acc);
-                acc = mfma32(*reinterpret_cast<const bf16x8*>(sqt + ((s2 * 2 + hh) * 32 + rq) * 8), pds, acc);
+                acc = mfma32(tr_frag2(ado + 128 * s2, ado + 128 * s2 + 64), pack8(s, s2), acc);
+                acc = mfma32(tr_frag2(aq + 128 * s2, aq + 128 * s2 + 64), pds, acc);
 #pragma unroll
                 for (int j = 0; j < 8; ++j)             // register 8*s2 + j holds query row acc32_row(8*s2 + j, hh) of this lane's key
-                    patch[acc32_row(8 * s2 + j, hh) * MMT_FUSED_PATCH_LD + pcol] = pds[j];
+                    patch[acc32_row(8 * s2 + j, hh) * MMT_FUSED_PATCH_LD + r] = pds[j];
             }
             FB_STAMP(2);                                // packs, dV/dK products, patch writes
-            // dQ^T share of this key tile: K^T (features x keys) times dS^T (keys x queries); lanes r >= 16 would produce the padding
-            // feature rows, which nobody reads, so they fetch the same K^T rows as lanes r - 16
+            // dQ^T share of this key tile: K^T (features x keys) times dS^T (keys x queries).  K^T fragments by transposing reads of
+            // the own K tile: slot j <-> key 16 s2 + 8 hh + j, the patch's column order; lanes r >= 16 would produce the padding
+            // feature rows, which nobody reads: they supply (and receive) the same as lanes r - 16
+            const bf16* const ak = reinterpret_cast<const bf16*>(kvl0 + wave * (2 * RT * 16)) + toff + 64 * hh;
             f32x16 dqp;
 #pragma unroll
             for (int j = 0; j < 16; ++j) dqp[j] = 0.f;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(patch + r * MMT_FUSED_PATCH_LD + 16 * s2 + 8 * hh);
-                const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(ktl0 + wave * 1024 + ((s2 * 2 + hh) * 16 + (r & 15)) * 16);
-                dqp = mfma32(afrag, bfrag, dqp);
+                dqp = mfma32(tr_frag2(ak + 128 * s2, ak + 128 * s2 + 32), bfrag, dqp);
             }
             float* const part = reinterpret_cast<float*>(region);
 #pragma unroll

@@ -67,6 +67,23 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
+// ---- transposing LDS reads (gfx950 ds_read_b64_tr_b16) ------------------------------------------------------------
+// Every lane supplies the address of an 8-byte chunk = 4 consecutive bf16 features of ONE row (window); inside a 16-lane group lane
+// 4q + p addresses row q of a 4-row block, features 4p .. 4p+3, and lane j of the group RECEIVES feature j of the block's four rows.
+// Two reads give a lane the 8 contraction elements of an MFMA operand fragment whose contraction index is the row — the operand
+// of a product that contracts over windows, read from a tile that is stored window-major.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+__device__ __forceinline__ bf16x8 tr_frag2(const bf16* p0, const bf16* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p1);
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// rows q and q + 4 of a tile with `row_stride` elements between rows
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* p, int row_stride) { return tr_frag2(p, p + 4 * row_stride); }
+
 // ---- fragment layout index maps (element offsets inside one (batch,head) matrix) ----------------
 // R layout: tile-major, then 8-feature chunk, then window-in-tile, then feature-in-chunk.
 __device__ __forceinline__ size_t fragR_index(int t, int e, int DKP) {

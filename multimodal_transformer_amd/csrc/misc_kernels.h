@@ -233,17 +233,6 @@ struct WgradJob {
 struct WgradJobs { WgradJob j[MMT_MAX_WGRAD_JOBS]; int njobs; int MP; int M16; int mchunk;
                    int tiles_per_layer, nlayers, nsplit; };    // > 0: 1-D XCD-aware grid (see wgrad_kernel); 0: grid = (tiles, splits)
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-// 8 contraction elements (windows 8hh .. 8hh+7 of a 16-window k-step) of this lane's feature, from a [window][feature] LDS tile
-__device__ __forceinline__ bf16x8 tr_frag(const bf16* p, int row_stride) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 4 * row_stride));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
-}
-
 __global__ __launch_bounds__(MMT_THREADS, 2) void wgrad_kernel(const WgradJobs jobs) {
     constexpr int LDR = 96;                                    // bf16 elements per LDS row (192 bytes)
     __shared__ __attribute__((aligned(16))) bf16 As[2][64 * LDR];

@@ -460,7 +460,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[i] = (bf16)v[i];
                     if (!fastT) *reinterpret_cast<bf16x4*>(p.fragR[wi] + bh * szR + fragR_index(t, e, p.DKP)) = o;
-                    if (!fastT) {
+                    if (!fastT && p.fragT[wi]) {
                         bf16* dT = p.fragT[wi] + bh * szT;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) dT[fragT_index(t, e + i, p.Tp)] = o[i];
@@ -508,7 +508,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                 //  T layout [tile][s][hh][e][j]: lanes across the columns (e); the 8 j of a 16-byte piece are windows
                 //  t..t+3 and t+8..t+11, i.e. row groups rg and rg+2 of this tile when both lie in it and in the sequence
                 const int c = tid & 127, nn = n0 + c;
-                if (nn < p.nwhich * HD) {
+                if (nn < p.nwhich * HD && p.fragT[col_pos(nn, HD, p.DKP).wi]) {          // (a matrix nobody reads transposed has no T array)
                     const ColPos cj = col_pos(nn, HD, p.DKP);
                     const int wj = cj.wi, hj = cj.head, ej = cj.e;
 #pragma unroll

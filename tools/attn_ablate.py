@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {0: "baseline", 1: "no running max / rescale / lane exchange", 2: "no exp", 3: "no PV product (MFMA)",
-         4: "operands from global memory: no LDS staging, no barrier", 5: "no row sums", 6: "stamped (correct results)"}
+         5: "no row sums", 6: "stamped (correct results)"}
 SEG = ["K read + QK^T + tile max + lane exchange", "rescale test + exp + row sums", "mask wait + selects", "V reads + packs + PV issue",
        "staged-tile load wait + LDS write", "barrier", "-", "loop top"]
 
