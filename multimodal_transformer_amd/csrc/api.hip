@@ -155,7 +155,7 @@ static bool use_fused_bwd(const EncDims& D) {
 
 struct LayerWs {
     float *xout, *x1, *stats1, *stats2, *lse;
-    bf16 *xn1, *xn2, *QR, *KR, *VR, *QT, *KT, *ctx, *hid;      // xn1, xn2, ctx, hid: row-major [MP][pad], operands of wgrad
+    bf16 *xn1, *xn2, *QR, *KR, *VR, *ctx, *hid;      // xn1, xn2, ctx, hid: row-major [MP][pad], operands of wgrad
     // backward operands of the weight-gradient GEMMs (row-major bf16 [MP][pad]), kept per layer so ONE batched launch forms every layer's dW
     bf16 *dx2, *dh, *dx1, *dqkv;
     float *lnpart1, *lnpart2;
@@ -166,7 +166,7 @@ struct EncWs {
     LayerWs lw[MAX_LAYERS];
     // backward scratch (shared by all layers; single stream)
     float *dxa, *dxb, *delta, *lnpartf;
-    bf16 *dOR, *dOT;
+    bf16 *dOR;
     float *sWqkv, *sbqkv, *sWo, *sbo, *sW1, *sb1, *sW2, *sb2;   // slab sets of layer 0; layer l at + l * slab_stride
     size_t slab_stride;
     size_t bytes;
@@ -187,8 +187,6 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
         w.xn1 = c.take<bf16>(MP * L.DP); w.xn2 = c.take<bf16>(MP * L.DP);          // MP rows: rows >= M stay zero for wgrad
         w.QR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP)); w.KR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP));
         w.VR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP));
-        const size_t nT = use_fused_bwd(D) ? 0 : BH * fragT_elems(D.Tp, L.DKP);       // no T layouts for the one-kernel backward
-        w.QT = nT ? c.take<bf16>(nT) : nullptr; w.KT = nT ? c.take<bf16>(nT) : nullptr;
         w.ctx = c.take<bf16>(MP * L.HDP); w.hid = c.take<bf16>(MP * L.FP);
         w.dx2 = c.take<bf16>(MP * L.DP); w.dh = c.take<bf16>(MP * L.FP);
         w.dx1 = c.take<bf16>(MP * L.DP); w.dqkv = c.take<bf16>(MP * L.NQ);
@@ -206,7 +204,6 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
     W.delta = c.take<float>(BH * D.Tp);
     W.lnpartf = c.take<float>((size_t)D.G * 2 * L.DP);
     W.dOR = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP));
-    W.dOT = use_fused_bwd(D) ? nullptr : c.take<bf16>(BH * fragT_elems(D.Tp, L.DKP));
     const size_t S = D.nsplit;
     {   // one slab set per layer, identical sizes: layer l's set lives at + l * slab_stride floats
         const size_t before = c.off;
@@ -316,8 +313,8 @@ static int launch_attn_fwd(int DKP, const bf16* QR, const bf16* KR, const bf16* 
 }
 
 // dQ, dK, dV -> bf16 row-major dqkv [M][NQ] (columns: dQ | dK | dV, heads padded)
-static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* KR, const bf16* KT_, const bf16* VR,
-                           const bf16* dOR, const bf16* dOT, const float* lse, const float* delta, const float* rowmask,
+static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* KR, const bf16* VR,
+                           const bf16* dOR, const float* lse, const float* delta, const float* rowmask,
                            bf16* dqkv, const EncDims& D, hipStream_t st, DropCfg drop = no_drop(),
                            const uint16_t* maskQ = nullptr, const uint16_t* maskK = nullptr) {
     dim3 grid(attn_grid((D.nt + 3) / 4, D.B * D.h));
@@ -352,7 +349,7 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
     {
         ProfScope prof(S_ATTN_BWD, st);
 #define MMT_DKV(dkp, dr) for (int fb = 0; fb < (dkp + 31) / 32; ++fb) \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, QT, KR, VR, dOR, dOT, lse, delta, \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VR, dOR, lse, delta, \
                            dqkv, D.L.NQ, D.h, D.T, D.nt, D.B * D.h, maskK, drop.scale, fb)
         if (DKP == 16) { if (drop.thr16) MMT_DKV(16, true); else MMT_DKV(16, false); }
         else if (DKP == 32) { if (drop.thr16) MMT_DKV(32, true); else MMT_DKV(32, false); }
@@ -363,7 +360,7 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* QT, const bf16* 
     {
         ProfScope prof(S_ATTN_BWD_DQ, st);
 #define MMT_DQ(dkp, dr) for (int fb = 0; fb < (dkp + 31) / 32; ++fb) \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, KT_, VR, dOR, lse, delta, rowmask, \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<dkp, dr>), grid, dim3(MMT_THREADS), 0, st, QR, KR, VR, dOR, lse, delta, rowmask, \
                            scale, dqkv, D.L.NQ, D.h, D.T, D.nt, D.B * D.h, maskQ, drop.scale, fb)
         if (DKP == 16) { if (drop.thr16) MMT_DQ(16, true); else MMT_DQ(16, false); }
         else if (DKP == 32) { if (drop.thr16) MMT_DQ(32, true); else MMT_DQ(32, false); }
@@ -438,7 +435,6 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
             p.ln_a = Pl + L.oln(0); p.ln_b = Pl + L.oln(1); p.eps = eps; p.stats = wl.stats1;
             p.W = W.wprep + (size_t)ll * L.pstride() + L.pWqkv(); p.bias = W.bprep + (size_t)ll * L.qstride() + L.qbqkv();
             p.fragR[0] = wl.QR; p.fragR[1] = wl.KR; p.fragR[2] = wl.VR;
-            p.fragT[0] = wl.QT; p.fragT[1] = wl.KT; p.fragT[2] = nullptr;      // V is only ever read window-major (attn_fwd: transposing LDS reads)
             p.T = T; p.Tp = D.Tp; p.h = h; p.DKP = L.DKP; p.nwhich = 3;
             p.rowmask = mask; p.qscale = LOG2E / sqrtf((float)L.dk); p.scale_first = 1;
             return p;
@@ -572,13 +568,13 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
                 p.A_out = w.dx1; p.lda_out = L.DP;
                 p.W = wp + L.pWoT();
                 p.a_drop = make_drop(dropout_p, seed, 4 * l + 1);   // gradient of the dropped sublayer-0 output
-                p.fragR[0] = W.dOR; p.fragT[0] = W.dOT;
+                p.fragR[0] = W.dOR;
                 p.T = T; p.Tp = D.Tp; p.h = h; p.DKP = L.DKP; p.nwhich = 1;
                 p.ctx = w.ctx; p.ldctx = L.HDP; p.delta = W.delta; }
             ch.ldx = L.DP + 4; ch.lda2 = L.FP + 8;
             if ((rc = launch_rowchain(encoder_pre_attn_bwd_kernel, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st))) return rc;
         }
-        if ((rc = launch_attn_bwd(L.DKP, w.QR, w.QT, w.KR, w.KT, w.VR, W.dOR, W.dOT, w.lse, W.delta, mask,
+        if ((rc = launch_attn_bwd(L.DKP, w.QR, w.KR, w.VR, W.dOR, w.lse, W.delta, mask,
                                   w.dqkv, D, st, make_drop(dropout_p, seed, 4 * l + 0), w.maskQ, w.maskK))) return rc;
         float* dxin = (l > 0) ? cur : dx;
         {   // dx = dx1 + LN1bwd(dQKV Wqkv)
@@ -659,7 +655,7 @@ extern "C" int mmt_layernorm_backward(const float* dy, const float* x, const flo
 
 // ------------------------------------------------------------------------------------ attention core alone
 // pack (B,T,d) fp32 head-major-column tensors into fragment layouts; unpack head-padded bf16 back.
-__global__ void pack_frag_kernel(const float* __restrict__ src, bf16* __restrict__ fr, bf16* __restrict__ ft,
+__global__ void pack_frag_kernel(const float* __restrict__ src, bf16* __restrict__ fr,
                                  const float* __restrict__ rowmask, float scale, int use_mask,
                                  const bf16* __restrict__ ctx, int ldctx, float* __restrict__ delta,
                                  int M, int T, int Tp, int h, int dk, int DKP, int d) {
@@ -673,7 +669,6 @@ __global__ void pack_frag_kernel(const float* __restrict__ src, bf16* __restrict
         for (int e = 0; e < dk; ++e) {
             const bf16 v = (bf16)(src[(size_t)m * d + head * dk + e] * sc);
             fr[bh * fragR_elems(Tp, DKP) + fragR_index(t, e, DKP)] = v;
-            if (ft) ft[bh * fragT_elems(Tp, DKP) + fragT_index(t, e, Tp)] = v;
             if (delta) part += (float)v * (float)ctx[(size_t)m * ldctx + head * DKP + e];
         }
         if (delta) delta[bh * Tp + t] = -part;       // stored negated, like the fused path
@@ -689,15 +684,13 @@ __global__ void unpad_heads_kernel(const bf16* __restrict__ src, int ld, int col
     }
 }
 
-struct SdpaWs { bf16 *QR, *QT, *KR, *KT, *VR, *dOR, *dOT, *ctx, *dqkv; float *lse, *delta; uint16_t *maskQ, *maskK; size_t bytes; };
+struct SdpaWs { bf16 *QR, *KR, *VR, *dOR, *ctx, *dqkv; float *lse, *delta; uint16_t *maskQ, *maskK; size_t bytes; };
 static void carve_sdpa(SdpaWs& W, const EncDims& D, void* base) {
     Carver c(base);
     const LayerLayout& L = D.L;
     const size_t BH = (size_t)D.B * D.h, M = D.M;
     bf16** r[] = {&W.QR, &W.KR, &W.VR, &W.dOR};
-    bf16** t[] = {&W.QT, &W.KT, &W.dOT};
     for (int i = 0; i < 4; ++i) *r[i] = c.take<bf16>(BH * fragR_elems(D.Tp, L.DKP));
-    for (int i = 0; i < 3; ++i) *t[i] = use_fused_bwd(D) ? nullptr : c.take<bf16>(BH * fragT_elems(D.Tp, L.DKP));
     W.ctx = c.take<bf16>(M * L.HDP);
     W.dqkv = c.take<bf16>(M * L.NQ);
     W.lse = c.take<float>(BH * D.Tp); W.delta = c.take<float>(BH * D.Tp);
@@ -732,9 +725,9 @@ extern "C" int mmt_sdpa_forward(const float* q, const float* k, const float* v, 
     const LayerLayout& L = D.L;
     const int g = grid_for((size_t)D.M * h);
     const float qs = LOG2E / sqrtf((float)L.dk);
-    hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, q, W.QR, W.QT, mask, qs, 1, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
-    hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, k, W.KR, W.KT, nullptr, 1.f, 0, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
-    hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, v, W.VR, nullptr, nullptr, 1.f, 0, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, q, W.QR, mask, qs, 1, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, k, W.KR, nullptr, 1.f, 0, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, v, W.VR, nullptr, 1.f, 0, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
     LAUNCH_CHECK("pack_frag_kernel");
     if (dropout_p > 0.f && (rc = launch_mask_gen(W.maskQ, W.maskK, D, 1, dropout_p, seed, st))) return rc;
     if ((rc = launch_attn_fwd(L.DKP, W.QR, W.KR, W.VR, W.ctx, W.lse, D, st, make_drop(dropout_p, seed, 0), W.maskQ))) return rc;
@@ -755,10 +748,10 @@ extern "C" int mmt_sdpa_backward(const float* dctx, const float* mask, float* dq
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const LayerLayout& L = D.L;
-    hipLaunchKernelGGL(pack_frag_kernel, dim3(grid_for((size_t)D.M * h)), dim3(256), 0, st, dctx, W.dOR, W.dOT, nullptr, 1.f, 0,
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(grid_for((size_t)D.M * h)), dim3(256), 0, st, dctx, W.dOR, nullptr, 1.f, 0,
                        W.ctx, L.HDP, W.delta, D.M, T, D.Tp, h, L.dk, L.DKP, d);
     LAUNCH_CHECK("pack_frag_kernel");
-    if ((rc = launch_attn_bwd(L.DKP, W.QR, W.QT, W.KR, W.KT, W.VR, W.dOR, W.dOT, W.lse, W.delta, mask, W.dqkv, D, st,
+    if ((rc = launch_attn_bwd(L.DKP, W.QR, W.KR, W.VR, W.dOR, W.lse, W.delta, mask, W.dqkv, D, st,
                               make_drop(dropout_p, seed, 0), W.maskQ, W.maskK))) return rc;     // the masks the forward generated
     const int g = grid_for((size_t)D.M * d);
     hipLaunchKernelGGL(unpad_heads_kernel, dim3(g), dim3(256), 0, st, W.dqkv, L.NQ, 0, dq, D.M, h, L.dk, L.DKP, d);

@@ -309,16 +309,18 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
 //     dS  = P * dPc ;  dV^T += dO^T P ;  dK^T += Q'^T dS     (P, dS accumulators ARE the B operands)
 template <int DKP, bool DROP>
 __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_kernel(
-        const bf16* __restrict__ Qr, const bf16* __restrict__ Qt, const bf16* __restrict__ Kr, const bf16* __restrict__ Vr,
-        const bf16* __restrict__ dOr, const bf16* __restrict__ dOt,
+        const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vr, const bf16* __restrict__ dOr,
         const float* __restrict__ lse, const float* __restrict__ delta,
         bf16* __restrict__ dkv, int lddkv,      // row-major [M][lddkv]; dK at column HD, dV at 2*HD
         int h, int T, int nt, int nbh, const uint16_t* __restrict__ maskK, float drop_scale, int fb) {
     constexpr int KS = DKP / 16;
     constexpr int DKB = DKP < 32 ? DKP : 32;
-    constexpr int PR = DKP * 4, PT = 128, PC = 8;       // pieces: R-layout tile, T-layout tile, 32 fp32 row constants
-    constexpr int TOTAL = 2 * PR + 2 * PT + 2 * PC;
-    __shared__ __attribute__((aligned(16))) bf16 stage[2][TOTAL * 8];
+    // pieces: R-layout tile (in LDS with its 8-feature groups 576 bytes apart: the products that contract over the queries read
+    // their A fragments out of these tiles with transposing reads, like attn_fwd_kernel reads V), 32 fp32 row constants
+    constexpr int PR = DKP * 4, PRL = (DKP / 8) * MMT_TR_OCT, PC = 8;
+    constexpr int TOTAL = 2 * PR + 2 * PC, TOTAL_LDS = 2 * PRL + 2 * PC;
+    __shared__ __attribute__((aligned(16))) bf16 stage[2][TOTAL_LDS * 8];
+    __shared__ __attribute__((aligned(16))) bf16 zeros[256];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const AttnBlock ab = attn_block((nt + 3) >> 2, nbh);
@@ -328,22 +330,22 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
     const int ktc = live ? kt : nt - 1;
     const int bh = ab.bh, b = bh / h, head = bh - b * h;
     const int Tp = nt * 32, HD = h * DKP;
-    const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp, DKP) + (size_t)fb * Tp * 32;
+    const size_t offR = (size_t)bh * fragR_elems(Tp, DKP);
     const bf16 *Krb = Kr + offR, *Vrb = Vr + offR;
     const uint16_t* mrow = maskK + ((size_t)bh * nt + ktc) * nt * 64 + lane;      // LK layout: this lane's word of one block per query tile
     uint32_t mw = DROP ? mrow[0] : 0u;
     const uint32_t scale_bits = __builtin_bit_cast(uint32_t, drop_scale);
 
-    TileStager<6, (TOTAL + MMT_THREADS - 1) / MMT_THREADS> stg;
+    TileStager<4, (TOTAL + MMT_THREADS - 1) / MMT_THREADS> stg;
     {
-        const bf16* base[6] = {Qr + offR, dOr + offR, Qt + offT, dOt + offT,
+        const bf16* base[4] = {Qr + offR, dOr + offR,
                                reinterpret_cast<const bf16*>(lse + (size_t)bh * Tp), reinterpret_cast<const bf16*>(delta + (size_t)bh * Tp)};
-        const int pieces[6] = {PR, PR, PT, PT, PC, PC}, strides[6] = {32 * DKP, 32 * DKP, 1024, 1024, 64, 64};
-        int lds0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 1; i < (int)(sizeof(pieces) / sizeof(pieces[0])); ++i) lds0[i] = lds0[i - 1] + pieces[i - 1];
+        const int pieces[4] = {PR, PR, PC, PC}, strides[4] = {32 * DKP, 32 * DKP, 64, 64};
+        const int lds0[4] = {0, PRL, 2 * PRL, 2 * PRL + PC}, pad[4] = {MMT_TR_OCT - 32, MMT_TR_OCT - 32, 0, 0};
         stg.init(base, pieces, strides, lds0, pad, threadIdx.x);
     }
     stg.load(0);
+    zeros[threadIdx.x] = (bf16)0.f;
     bf16x8 kfr[KS], vfr[KS];
 #pragma unroll
     for (int ss = 0; ss < KS; ++ss) {
@@ -351,14 +353,17 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
         kfr[ss] = *reinterpret_cast<const bf16x8*>(Krb + off);
         vfr[ss] = *reinterpret_cast<const bf16x8*>(Vrb + off);
     }
-    // DKP == 16: the T-layout tiles carry 32 feature rows of which rows 16..31 are zero, so ONE accumulator serves both products:
-    // dO^T as stored fills rows 0..15 (dV^T), and Q^T read with its rows rotated by 16 (lane r fetches row r ^ 16) fills rows 16..31
-    // (dK^T).  16 VGPRs less puts the kernel at 4 waves per SIMD.  DKP == 32 keeps two accumulators.
+    // DKP == 16: a 32-row A fragment has 16 idle rows, so ONE accumulator serves both products: lanes r < 16 read dO^T (rows 0..15:
+    // dV^T) and zeros for Q^T, lanes r >= 16 read Q^T features r - 16 (rows 16..31: dK^T) and zeros for dO^T.  16 VGPRs less
+    // puts the kernel at 4 waves per SIMD.  DKP >= 32 keeps two accumulators.
     constexpr bool ONEACC = (DKP == 16);
     f32x16 dKacc, dVacc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) { dKacc[j] = 0.f; dVacc[j] = 0.f; }
-    const int rq = ONEACC ? (r ^ 16) : r;
+    // transposing-read role (see attn_fwd_kernel): the lane supplies query tq of a 4-query block, features 4 tpp .. + 3 of its
+    // 16-lane group's 16 features, and receives feature row r; slot j <-> query 16 s2 + 8 (j >> 2) + 4 hh + (j & 3)
+    const int g1 = (lane >> 4) & 1, tq = (lane >> 2) & 3, tpp = lane & 3;
+    const int toff = (((ONEACC ? 0 : 4 * fb + 2 * g1) + (tpp >> 1)) * MMT_TR_OCT + 4 * hh + tq) * 8 + 4 * (tpp & 1);
     const bool key_tail = (ktc == nt - 1) && (T & 31);
     const bool key_ok = (ktc * 32 + r) < T;
     stg.store(stage[0]);
@@ -375,11 +380,11 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
         if (DROP && more) mw = mrow[(size_t)(qt + 1) * 64];
         if (more) stg.load(qt + 1);
         const bf16* sq = stage[qt & 1];
-        const bf16* sdo = sq + PR * 8;
-        const bf16* sqt = sq + 2 * PR * 8;
-        const bf16* sdt = sqt + PT * 8;
-        const float* sl = reinterpret_cast<const float*>(sdt + PT * 8);
+        const bf16* sdo = sq + PRL * 8;
+        const float* sl = reinterpret_cast<const float*>(sq + 2 * PRL * 8);
         const float* sd = sl + 32;
+        const bf16* ado = (ONEACC && g1) ? zeros : sdo + toff;
+        const bf16* aq = (ONEACC && !g1) ? zeros : sq + toff;
         f32x16 s, dp;                   // row constants (4 consecutive queries per register group) as the accumulators
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
         }
 #pragma unroll
         for (int ss = 0; ss < KS; ++ss) {
-            const int o8 = ((2 * ss + hh) * 32 + r) * 8;
+            const int o8 = ((2 * ss + hh) * MMT_TR_OCT + r) * 8;
             s = mfma32(*reinterpret_cast<const bf16x8*>(sq + o8), kfr[ss], s);
             dp = mfma32(*reinterpret_cast<const bf16x8*>(sdo + o8), vfr[ss], dp);
         }
@@ -425,10 +430,9 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const int o8 = ((s2 * 2 + hh) * 32 + r) * 8;
-            dVacc = mfma32(*reinterpret_cast<const bf16x8*>(sdt + o8), pack8(s, s2), dVacc);
-            if (ONEACC) dVacc = mfma32(*reinterpret_cast<const bf16x8*>(sqt + ((s2 * 2 + hh) * 32 + rq) * 8), pack8(dp, s2), dVacc);
-            else dKacc = mfma32(*reinterpret_cast<const bf16x8*>(sqt + o8), pack8(dp, s2), dKacc);
+            dVacc = mfma32(tr_frag2(ado + 128 * s2, ado + 128 * s2 + 64), pack8(s, s2), dVacc);
+            if (ONEACC) dVacc = mfma32(tr_frag2(aq + 128 * s2, aq + 128 * s2 + 64), pack8(dp, s2), dVacc);
+            else dKacc = mfma32(tr_frag2(aq + 128 * s2, aq + 128 * s2 + 64), pack8(dp, s2), dKacc);
         }
         if (more) stg.store(stage[(qt + 1) & 1]);
         __syncthreads();
@@ -463,15 +467,15 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
 // query-row mask (blanked rows pass no gradient to Q) and writes columns [0,HD) of dQKV in both layouts.
 template <int DKP, bool DROP>
 __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
-        const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Kt, const bf16* __restrict__ Vr,
+        const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vr,
         const bf16* __restrict__ dOr, const float* __restrict__ lse, const float* __restrict__ delta,
         const float* __restrict__ rowmask, float scale,
         bf16* __restrict__ dqkv, int lddqkv,
         int h, int T, int nt, int nbh, const uint16_t* __restrict__ maskQ, float drop_scale, int fb) {
     constexpr int KS = DKP / 16;
     constexpr int DKB = DKP < 32 ? DKP : 32;
-    constexpr int PR = DKP * 4, PT = 128;
-    __shared__ __attribute__((aligned(16))) bf16 stage[2][(2 * PR + PT) * 8];
+    constexpr int PR = DKP * 4, PRL = (DKP / 8) * MMT_TR_OCT;      // K tile padded in LDS: K^T fragments by transposing reads
+    __shared__ __attribute__((aligned(16))) bf16 stage[2][(PRL + PR) * 8];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const AttnBlock ab = attn_block((nt + 3) >> 2, nbh);
@@ -481,21 +485,23 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
     const int qtc = live ? qt : nt - 1;
     const int bh = ab.bh, b = bh / h, head = bh - b * h;
     const int Tp = nt * 32;
-    const size_t offR = (size_t)bh * fragR_elems(Tp, DKP), offT = (size_t)bh * fragT_elems(Tp, DKP) + (size_t)fb * Tp * 32;
+    const size_t offR = (size_t)bh * fragR_elems(Tp, DKP);
     const bf16 *Qrb = Qr + offR, *dOrb = dOr + offR;
     const uint16_t* mrow = maskQ + ((size_t)bh * nt + qtc) * nt * 64 + lane;      // LQ layout
     uint32_t mw = DROP ? mrow[0] : 0u;
     const uint32_t scale_bits = __builtin_bit_cast(uint32_t, drop_scale);
 
-    TileStager<3, (2 * PR + PT + MMT_THREADS - 1) / MMT_THREADS> stg;
+    TileStager<2, (2 * PR + MMT_THREADS - 1) / MMT_THREADS> stg;
     {
-        const bf16* base[3] = {Kr + offR, Vr + offR, Kt + offT};
-        const int pieces[3] = {PR, PR, PT}, strides[3] = {32 * DKP, 32 * DKP, 1024};
-        int lds0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pad[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 1; i < (int)(sizeof(pieces) / sizeof(pieces[0])); ++i) lds0[i] = lds0[i - 1] + pieces[i - 1];
+        const bf16* base[2] = {Kr + offR, Vr + offR};
+        const int pieces[2] = {PR, PR}, strides[2] = {32 * DKP, 32 * DKP}, lds0[2] = {0, PRL}, pad[2] = {MMT_TR_OCT - 32, 0};
         stg.init(base, pieces, strides, lds0, pad, threadIdx.x);
     }
     stg.load(0);
+    // transposing-read role (see attn_fwd_kernel): feature row 32 fb + r of K^T; slot j <-> key 16 s2 + 8 (j >> 2) + 4 hh + (j & 3).
+    // d_k = 16: the lanes of rows >= 16 (nobody reads their dQ^T rows) fetch what lanes r - 16 fetch.
+    const int g1 = (lane >> 4) & 1, tq = (lane >> 2) & 3, tpp = lane & 3;
+    const int toff = (((DKP == 16 ? 0 : 4 * fb + 2 * g1) + (tpp >> 1)) * MMT_TR_OCT + 4 * hh + tq) * 8 + 4 * (tpp & 1);
     bf16x8 qf[KS], dof[KS];
 #pragma unroll
     for (int ss = 0; ss < KS; ++ss) {
@@ -520,8 +526,8 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
         if (DROP && more) mw = mrow[(size_t)(kt + 1) * 64];
         if (more) stg.load(kt + 1);
         const bf16* sk = stage[kt & 1];
-        const bf16* sv = sk + PR * 8;
-        const bf16* skt = sv + PR * 8;
+        const bf16* sv = sk + PRL * 8;
+        const bf16* skt = sk + toff;
         f32x16 s, dp;
         fill16(s, negL);
         if (DROP) {                                     // -delta enters after the mask
@@ -531,7 +537,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
 #pragma unroll
         for (int ss = 0; ss < KS; ++ss) {
             const int o8 = ((2 * ss + hh) * 32 + r) * 8;
-            s = mfma32(*reinterpret_cast<const bf16x8*>(sk + o8), qf[ss], s);
+            s = mfma32(*reinterpret_cast<const bf16x8*>(sk + o8 + (2 * ss + hh) * (MMT_TR_OCT - 32) * 8), qf[ss], s);
             dp = mfma32(*reinterpret_cast<const bf16x8*>(sv + o8), dof[ss], dp);
         }
 #pragma unroll
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
-            dq = mfma32(*reinterpret_cast<const bf16x8*>(skt + ((s2 * 2 + hh) * 32 + r) * 8), pack8(dp, s2), dq);
+            dq = mfma32(tr_frag2(skt + 128 * s2, skt + 128 * s2 + 64), pack8(dp, s2), dq);
         if (more) stg.store(stage[(kt + 1) & 1]);
         __syncthreads();
     };

@@ -89,14 +89,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* p, int row_stride) { retur
 __device__ __forceinline__ size_t fragR_index(int t, int e, int DKP) {
     return ((size_t)(t >> 5) * (DKP >> 3) + (e >> 3)) * 256 + (size_t)(t & 31) * 8 + (e & 7);
 }
-// T layout: feature blocks of 32 rows, whole blocks always stored (rows >= DKP of the single block at DKP < 32 stay zero);
-// block e >> 5 starts Tp * 32 elements after block 0 (only d_k = 64 has a second block).
-__device__ __forceinline__ size_t fragT_index(int t, int e, int Tp) {
-    const int s = (t >> 4) & 1, hh = (t >> 2) & 1, j = 4 * ((t >> 3) & 1) + (t & 3);
-    return (size_t)(e >> 5) * Tp * 32 + ((((size_t)(t >> 5) * 2 + s) * 2 + hh) * 32 + (e & 31)) * 8 + j;
-}
 __host__ __device__ __forceinline__ size_t fragR_elems(int Tp, int DKP) { return (size_t)Tp * DKP; }
-__host__ __device__ __forceinline__ size_t fragT_elems(int Tp, int DKP) { return (size_t)Tp * (DKP > 32 ? DKP : 32); }
 
 __host__ __device__ __forceinline__ int round_up(int x, int m) { return (x + m - 1) / m * m; }
 

@@ -79,7 +79,7 @@ struct RowGemmParams {
     float* out_f32; int ldo;
     bf16* out_bf16; int ldo16; int n_store16;   // columns [0, n_store16) are written (pads come out as exact zeros)
     // ---- FRAG ----
-    bf16* fragR[3]; bf16* fragT[3];
+    bf16* fragR[3];
     int T, Tp, h, DKP, nwhich;             // N covers nwhich * h * DKP columns
     const float* rowmask; float qscale; int scale_first;   // first matrix: *qscale and zero where rowmask==0
     const bf16* ctx; int ldctx; float* delta;              // delta[bh][Tp] = -sum_e C*ctx (dO epilogue; stored negated)
@@ -419,119 +419,70 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                 }
             }
         } else if (EPI == EPI_FRAG) {
+            // Output: the R fragment layout [batch*head][tile][e>>3][t&31][e&7] — the only layout the attention kernels read.
+            // The store pass lays the lanes along the tile's windows: 16 bytes per lane, 512-byte runs per 8-feature group
+            // (8-byte stores with the lanes across columns cost one write transaction per lane).
             const int HD = p.h * p.DKP;
-            const size_t szR = fragR_elems(p.Tp, p.DKP), szT = fragT_elems(p.Tp, p.DKP);
-            const int nred = p.DKP >> 2;                 // lanes per head (4, 8 or 16), aligned groups
-            const bool fastT = (p.T & 3) == 0;           // 4 consecutive windows of a tile row group share (batch, s, hh): 8-byte T stores
-            const int cg = tid & 31, n = n0 + cg * 4, rbase = tid >> 5;
-            const bool col_ok = n < p.nwhich * HD;
-            const ColPos cp = col_pos(col_ok ? n : 0, HD, p.DKP);
-            const int wi = cp.wi, rem = cp.rem, head = cp.head, e = cp.e;
+            const size_t szR = fragR_elems(p.Tp, p.DKP);
             // first row of the tile in (sequence, window) form: one wave-uniform division per stage
             const int tb0 = __builtin_amdgcn_readfirstlane(m0 / p.T), tt0 = m0 - tb0 * p.T;
-            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-            if (col_ok && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-            // phase 1: all global loads of the 4 tasks
-            float sc[MMT_RIT];
-            bf16x4 c4[MMT_RIT];
+            if (p.delta) {
+                // dO epilogue: delta = rowsum(dO . O) per (window, head) needs the row-wise thread mapping first: round to bf16, take the
+                // partial sums over the head's lanes, and leave the rounded values in the tile for the store pass
+                const int nred = p.DKP >> 2;             // lanes per head (4, 8 or 16), aligned groups
+                const int cg = tid & 31, n = n0 + cg * 4, rbase = tid >> 5;
+                const bool col_ok = n < p.nwhich * HD;
+                const ColPos cp = col_pos(col_ok ? n : 0, HD, p.DKP);
+                f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+                if (col_ok && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                bf16x4 c4[MMT_RIT];
 #pragma unroll
-            for (int it = 0; it < MMT_RIT; ++it) {
-                const int m = m0 + rbase + MMT_RSTEP * it;
-                sc[it] = 1.f;
-                if (col_ok && m < M) {
-                    if (p.scale_first && wi == 0) sc[it] = (p.rowmask[m] == 0.0f) ? 0.f : p.qscale;   // mask == 0 -> blank query row
-                    if (p.delta) c4[it] = *reinterpret_cast<const bf16x4*>(p.ctx + (size_t)m * p.ldctx + rem);
+                for (int it = 0; it < MMT_RIT; ++it) {
+                    const int m = m0 + rbase + MMT_RSTEP * it;
+                    if (col_ok && m < M) c4[it] = *reinterpret_cast<const bf16x4*>(p.ctx + (size_t)m * p.ldctx + cp.rem);
                 }
-            }
 #pragma unroll
-            for (int it = 0; it < MMT_RIT; ++it) {
-                const int row = rbase + MMT_RSTEP * it, m = m0 + row;
-                const bool ok = col_ok && (m < M);
-                float part = 0.f;
-                int bh = 0, t = 0;
-                bf16x4 o = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-                if (ok) {
-                    const SeqPos sp = seq_pos(tb0, tt0, row, p.T);
-                    t = sp.t;
-                    bh = sp.b * p.h + head;
-                    f32x4 v = *reinterpret_cast<const f32x4*>(Fs + row * ldf + cg * 4);
-                    v += bias4;
-                    v *= sc[it];
+                for (int it = 0; it < MMT_RIT; ++it) {
+                    const int row = rbase + MMT_RSTEP * it, m = m0 + row;
+                    const bool ok = col_ok && (m < M);
+                    float part = 0.f;
+                    f32x4 w = {0.f, 0.f, 0.f, 0.f};
+                    if (ok) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(Fs + row * ldf + cg * 4);
+                        v += bias4;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (bf16)v[i];
-                    if (!fastT) *reinterpret_cast<bf16x4*>(p.fragR[wi] + bh * szR + fragR_index(t, e, p.DKP)) = o;
-                    if (!fastT && p.fragT[wi]) {
-                        bf16* dT = p.fragT[wi] + bh * szT;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) dT[fragT_index(t, e + i, p.Tp)] = o[i];
+                        for (int i = 0; i < 4; ++i) { const bf16 o = (bf16)v[i]; w[i] = (float)o; part += w[i] * (float)c4[it][i]; }
                     }
-                    if (p.delta) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) part += (float)o[i] * (float)c4[it][i];
-                    }
-                }
-                if (fastT) {                             // bf16-rounded values back to the tile for the transposed pass
-                    f32x4 w;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) w[i] = (float)o[i];
                     *reinterpret_cast<f32x4*>(Fs + row * ldf + cg * 4) = w;
-                }
-                if (p.delta) {
                     part += __shfl_xor(part, 1); part += __shfl_xor(part, 2);
                     if (nred >= 8) part += __shfl_xor(part, 4);
                     if (nred == 16) part += __shfl_xor(part, 8);
-                    if (ok && e == 0) p.delta[(size_t)bh * p.Tp + t] = -part;      // stored negated (accumulator init of the backward)
-                }
-            }
-            if (fastT) {
-                __syncthreads();
-                // The tile now holds the final bf16-rounded values.  Both fragment layouts are written with lanes laid along
-                // the direction that is contiguous in memory (8-byte stores with the lanes across columns cost one write
-                // transaction per lane: 2.5 M transactions per QKV launch at C4):
-                //  R layout [tile][e>>3][t&31][e&7]: lanes across the tile's windows -> 16 bytes per lane, 256/512-byte runs
-#pragma unroll
-                for (int it = 0; it < (MMT_ROWS * 16 + MMT_RTHREADS - 1) / MMT_RTHREADS; ++it) {
-                    const int q = tid + it * MMT_RTHREADS, rr = q % MMT_ROWS, cc = q / MMT_ROWS, nn = n0 + 8 * cc, mm = m0 + rr;
-                    if (cc < 16 && nn < p.nwhich * HD && mm < M) {
-                        const ColPos cj = col_pos(nn, HD, p.DKP);
-                        const int wj = cj.wi, hj = cj.head, ej = cj.e;
-                        const SeqPos sp = seq_pos(tb0, tt0, rr, p.T);
-                        const int b = sp.b, t = sp.t;
-                        const f32x4 lo = *reinterpret_cast<const f32x4*>(Fs + rr * ldf + 8 * cc);
-                        const f32x4 hi = *reinterpret_cast<const f32x4*>(Fs + rr * ldf + 8 * cc + 4);
-                        bf16x8 o;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) { o[i] = (bf16)lo[i]; o[4 + i] = (bf16)hi[i]; }
-                        *reinterpret_cast<bf16x8*>(p.fragR[wj] + (size_t)(b * p.h + hj) * szR + fragR_index(t, ej, p.DKP)) = o;
+                    if (ok && cp.e == 0) {
+                        const SeqPos sp = seq_pos(tb0, tt0, row, p.T);
+                        p.delta[(size_t)(sp.b * p.h + cp.head) * p.Tp + sp.t] = -part;      // stored negated (accumulator init of the backward)
                     }
                 }
-                //  T layout [tile][s][hh][e][j]: lanes across the columns (e); the 8 j of a 16-byte piece are windows
-                //  t..t+3 and t+8..t+11, i.e. row groups rg and rg+2 of this tile when both lie in it and in the sequence
-                const int c = tid & 127, nn = n0 + c;
-                if (nn < p.nwhich * HD && p.fragT[col_pos(nn, HD, p.DKP).wi]) {          // (a matrix nobody reads transposed has no T array)
+                __syncthreads();
+            }
+#pragma unroll
+            for (int it = 0; it < (MMT_ROWS * 16 + MMT_RTHREADS - 1) / MMT_RTHREADS; ++it) {
+                const int q = tid + it * MMT_RTHREADS, rr = q % MMT_ROWS, cc = q / MMT_ROWS, nn = n0 + 8 * cc, mm = m0 + rr;
+                if (cc < 16 && nn < p.nwhich * HD && mm < M) {
                     const ColPos cj = col_pos(nn, HD, p.DKP);
-                    const int wj = cj.wi, hj = cj.head, ej = cj.e;
-#pragma unroll
-                    for (int it = 0; it < (MMT_ROWS / 4) / (MMT_RTHREADS / 128); ++it) {
-                        const int rg = (tid >> 7) + (MMT_RTHREADS / 128) * it, mg = m0 + 4 * rg;
-                        if (mg >= M) continue;
-                        const SeqPos sp = seq_pos(tb0, tt0, 4 * rg, p.T);
-                        const int b = sp.b, t = sp.t;
-                        const bool second = (t >> 3) & 1;                    // this row group is the j = 4..7 half of its piece
-                        if (second && rg >= 2) continue;                     // written by row group rg-2 (same tile, same sequence)
-                        bf16* dst = p.fragT[wj] + (size_t)(b * p.h + hj) * szT + fragT_index(t, ej, p.Tp);
-                        bf16x4 o;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) o[i] = (bf16)Fs[(4 * rg + i) * ldf + c];
-                        if (!second && rg + 2 < MMT_ROWS / 4 && t + 8 < p.T) {
-                            bf16x8 o8;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) { o8[i] = o[i]; o8[4 + i] = (bf16)Fs[(4 * rg + 8 + i) * ldf + c]; }
-                            *reinterpret_cast<bf16x8*>(dst) = o8;
-                        } else {
-                            *reinterpret_cast<bf16x4*>(dst) = o;
+                    const SeqPos sp = seq_pos(tb0, tt0, rr, p.T);
+                    f32x4 lo = *reinterpret_cast<const f32x4*>(Fs + rr * ldf + 8 * cc);
+                    f32x4 hi = *reinterpret_cast<const f32x4*>(Fs + rr * ldf + 8 * cc + 4);
+                    if (!p.delta) {                      // QKV epilogue: bias, and for Q the softmax scale and the query-row mask
+                        if (p.bias) { lo += *reinterpret_cast<const f32x4*>(p.bias + nn); hi += *reinterpret_cast<const f32x4*>(p.bias + nn + 4); }
+                        if (p.scale_first && cj.wi == 0) {
+                            const float sc = (p.rowmask[mm] == 0.0f) ? 0.f : p.qscale;       // mask == 0 -> blank query row
+                            lo *= sc; hi *= sc;
                         }
                     }
+                    bf16x8 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { o[i] = (bf16)lo[i]; o[4 + i] = (bf16)hi[i]; }
+                    *reinterpret_cast<bf16x8*>(p.fragR[cj.wi] + (size_t)(sp.b * p.h + cj.head) * szR + fragR_index(sp.t, cj.e, p.DKP)) = o;
                 }
             }
         }
