@@ -121,11 +121,14 @@ static int make_dims(EncDims& D, int B, int T, int d, int h, int f, int N) {
         // launch_rowgemm), so a shape fails at the workspace query and never half-way through a training step
         const LayerLayout& L = D.L;
         const int kmax = std::max(std::max(L.DP, L.FP), L.HDP), fw = std::max(128, L.DP);
-        const size_t bwd_chain = (size_t)MMT_ROWS * ((kmax + 8) * 2 + (fw + 4) * 4 * 2 + (L.DP + 4) * 4 + (L.FP + 8) * 2);
-        const size_t bwd_qkv = rowgemm_lds_bytes(EPI_LNBWD, false, L.NQ, L.DP);
-        if (bwd_chain > 160 * 1024 || bwd_qkv > 160 * 1024)
-            return fail(MMT_EUNSUPPORTED, "d_model %d / d_ff %d: a %d-window tile of the backward row kernels needs %zu B of LDS (160 KB per CU)",
-                        d, f, MMT_ROWS, std::max(bwd_chain, bwd_qkv));
+        const bool no_gs = L.DP > 128;
+        const size_t bwd_chain = (size_t)MMT_ROWS * ((kmax + 8) * 2 + (fw + 4) * 4 * (no_gs ? 1 : 2) + (L.FP + 8) * 2);
+        const size_t fwd_chain = (size_t)MMT_ROWS * ((kmax + 8) * 2 + (128 + 4) * 4 + (L.DP + 4) * 4 + (L.FP + 8) * 2);
+        const size_t bwd_qkv = rowgemm_lds_bytes(EPI_LNBWD, false, L.NQ, L.DP, L.NQ > 512 ? 512 : 0, no_gs);
+        const size_t worst = std::max(std::max(bwd_chain, fwd_chain), bwd_qkv);
+        if (worst > 160 * 1024)
+            return fail(MMT_EUNSUPPORTED, "d_model %d / d_ff %d: a %d-window tile of the row kernels needs %zu B of LDS (160 KB per CU)",
+                        d, f, MMT_ROWS, worst);
     }
     // weight-gradient split over windows: ONE launch covers every layer.  The launch deals (layer, split) units of `tpl` tiles
     // round-robin to the 8 XCDs (wgrad_kernel), and an XCD holds 32 CUs x 3 workgroups (48 KB of LDS each) at a time: pick the
@@ -219,19 +222,22 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
 }
 
 // ------------------------------------------------------------------------------------ launch helpers
-template <int EPI, bool LN>
+template <int EPI, bool LN, bool CHUNKS = false>
 static int launch_rowgemm(const RowGemmParams& p, hipStream_t st, int site = S_OTHER) {
-    const size_t lds = rowgemm_lds_bytes(EPI, LN, p.KP, p.NP);
+    if (!CHUNKS && p.kchunk > 0 && p.kchunk < p.KP) return launch_rowgemm<EPI, LN, true>(p, st, site);     // K-chunked staging: its own instance
+    const size_t lds = rowgemm_lds_bytes(EPI, LN, p.KP, p.NP, p.kchunk, p.no_gs != 0);
     if (lds > 160 * 1024) return fail(MMT_EUNSUPPORTED, "row GEMM tile needs %zu B of LDS (K=%d, N=%d)", lds, p.K, p.N);
+    if (CHUNKS && (!p.a_bf16 || (p.kchunk & (p.kchunk - 1)) || p.kchunk < 64 || p.A_out))
+        return fail(MMT_EINVAL, "K-chunked staging needs a bf16 A matrix, a power-of-two chunk >= 64 and no A copy");
     static size_t configured = 0;           // per instantiation
     if (lds > configured) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<EPI, LN>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<EPI, LN, CHUNKS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = 160 * 1024;
     }
     const int grid = (p.M + MMT_ROWS - 1) / MMT_ROWS;
     ProfScope prof(site, st);
-    hipLaunchKernelGGL((rowgemm_kernel<EPI, LN>), dim3(grid), dim3(MMT_RTHREADS), lds, st, p);
+    hipLaunchKernelGGL((rowgemm_kernel<EPI, LN, CHUNKS>), dim3(grid), dim3(MMT_RTHREADS), lds, st, p);
     LAUNCH_CHECK("rowgemm_kernel");
     return MMT_OK;
 }
@@ -240,15 +246,16 @@ static int chain_extra_kp(const RowChain3&) { return 0; }
 static int chain_extra_kp(const RowChain4& ch) { return ch.d.KP; }
 
 template <typename K, typename CH>
-static int launch_rowchain(K kernel, CH& ch, bool with_g, int site, const char* name, hipStream_t st) {
+static int launch_rowchain(K kernel, CH& ch, bool lnbwd, int site, const char* name, hipStream_t st) {   // lnbwd: stage b is a LayerNorm backward
     // LDS geometry shared by the stages
     int kmax = ch.a.KP > ch.b.KP ? ch.a.KP : ch.b.KP;             // stages reading sm.As: a (global) and whichever of b/c stages via Xs
     if (ch.c.KP > kmax) kmax = ch.c.KP;
     if (chain_extra_kp(ch) > kmax) kmax = chain_extra_kp(ch);
     ch.lda_max = kmax + 8;
     int fw = 128;
-    if (with_g && ch.b.NP > fw) fw = ch.b.NP;                  // LayerNorm-backward epilogue needs the full row
+    if (lnbwd && ch.b.NP > fw) fw = ch.b.NP;                   // LayerNorm-backward epilogue needs the full row
     ch.ldf = fw + 4;
+    const bool with_g = lnbwd && !ch.b.no_gs;                  // ... and a second fp32 tile unless the column sums recompute x-hat
     const size_t lds = rowchain_lds_bytes(ch, with_g);
     if (lds > 160 * 1024) return fail(MMT_EUNSUPPORTED, "fused row chain needs %zu B of LDS", lds);
     static const void* configured[4] = {nullptr, nullptr, nullptr, nullptr};     // both chain kernels share this instantiation
@@ -562,16 +569,18 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
                 p.M = D.M; p.K = L.FP; p.KP = L.FP; p.N = d; p.NP = L.DP;
                 p.W = wp + L.pW1T();
                 p.x = w.x1; p.ldx = d; p.st = w.stats2; p.ln_a = P + L.oln(2); p.eps = eps; p.d_real = d;
-                p.dres = cur; p.lddres = d; p.out_f32 = other; p.ldo = d; p.colpart = w.lnpart2; }
+                p.dres = cur; p.lddres = d; p.out_f32 = other; p.ldo = d; p.colpart = w.lnpart2;
+                p.no_gs = L.DP > 128;                               // d_model > 128: a second fp32 tile would leave one workgroup per CU
+                p.next_drop = make_drop(dropout_p, seed, 4 * l + 1);   // gradient of the dropped sublayer-0 output, applied to the next A tile
+                p.next_lda = L.DP + 8; }
             {   RowGemmParams& p = ch.c; p = rg_zero();           // dO = drop'(dx1) Wo -> fragments + delta   [emits dx1 as bf16 rows]
                 p.M = D.M; p.K = d; p.KP = L.DP; p.N = L.HD; p.NP = L.HDP;
-                p.A_out = w.dx1; p.lda_out = L.DP;
+                p.A_out = w.dx1; p.lda_out = L.DP;                 // (its A tile, drop'(dx1) in bf16, was left in LDS by the stage before)
                 p.W = wp + L.pWoT();
-                p.a_drop = make_drop(dropout_p, seed, 4 * l + 1);   // gradient of the dropped sublayer-0 output
                 p.fragR[0] = W.dOR;
                 p.T = T; p.Tp = D.Tp; p.h = h; p.DKP = L.DKP; p.nwhich = 1;
                 p.ctx = w.ctx; p.ldctx = L.HDP; p.delta = W.delta; }
-            ch.ldx = L.DP + 4; ch.lda2 = L.FP + 8;
+            ch.ldx = 0; ch.lda2 = L.FP + 8;                        // no fp32 tile kept between the stages
             if ((rc = launch_rowchain(encoder_pre_attn_bwd_kernel, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st))) return rc;
         }
         if ((rc = launch_attn_bwd(L.DKP, w.QR, w.KR, w.VR, W.dOR, w.lse, W.delta, mask,
@@ -584,6 +593,8 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             p.W = wp + L.pWqkvT();
             p.x = xin; p.ldx = d; p.st = w.stats1; p.ln_a = P + L.oln(0); p.eps = eps; p.d_real = d;
             p.dres = other; p.lddres = d; p.out_f32 = dxin; p.ldo = d; p.colpart = w.lnpart1;
+            p.no_gs = L.DP > 128;
+            p.kchunk = (L.NQ > 512) ? 512 : 0;                     // d_model = 256: K = 768; half of the A tile in LDS at a time
             if ((rc = launch_rowgemm<EPI_LNBWD, false>(p, st, S_BWD_QKV_LN1))) return rc;
         }
         // weight-gradient jobs of this layer (run later, all layers in one launch)

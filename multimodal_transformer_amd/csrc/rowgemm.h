@@ -87,6 +87,10 @@ struct RowGemmParams {
     const float* x; int ldx; const float* st; const float* dres; int lddres;
     float* colpart;                        // [gridDim.x][2][NP]: per-workgroup column sums (d ln_b, d ln_a)
     int d_real;
+    int no_gs;                             // column sums of dy * x-hat recompute x-hat from x instead of reading a second fp32 tile (Gs)
+    DropCfg next_drop; int next_lda;       // KEEP_AS: the next stage's A tile = bf16(drop(out)) is left in As with this row stride
+    // ---- K-chunked A staging (bf16 A from global): only `kchunk` (a power of two >= 64) columns of the A tile are in LDS at a time
+    int kchunk;                            // 0: the whole K
 };
 
 __host__ __device__ inline int rowgemm_fw(int EPI, bool lnpro, int KP, int NP) {
@@ -95,18 +99,18 @@ __host__ __device__ inline int rowgemm_fw(int EPI, bool lnpro, int KP, int NP) {
     if (lnpro && KP > fw) fw = KP;
     return fw;
 }
-inline size_t rowgemm_lds_bytes(int EPI, bool lnpro, int KP, int NP) {
-    size_t a = (size_t)MMT_ROWS * (KP + 8) * 2;
+inline size_t rowgemm_lds_bytes(int EPI, bool lnpro, int KP, int NP, int kchunk = 0, bool no_gs = false) {
+    size_t a = (size_t)MMT_ROWS * ((kchunk > 0 && kchunk < KP ? kchunk : KP) + 8) * 2;
     size_t f = (size_t)MMT_ROWS * (rowgemm_fw(EPI, lnpro, KP, NP) + 4) * 4;
-    size_t g = (EPI == EPI_LNBWD) ? (size_t)MMT_ROWS * (NP + 4) * 4 : 0;
+    size_t g = (EPI == EPI_LNBWD && !no_gs) ? (size_t)MMT_ROWS * (NP + 4) * 4 : 0;
     return a + f + g;
 }
 
 // A stage = one row-local GEMM with its prologue and epilogue.  Stages can be chained inside one kernel: the
 // 32-window tile then stays in LDS between them (Xs: fp32 tile of the residual stream / a gradient; A2: bf16 tile
 // ready to be the next A operand) instead of making a round trip through L2 and a kernel boundary.
-enum { ASRC_GLOBAL = 0, ASRC_X = 1, ASRC_A2 = 2 };           // where the A operand comes from
-enum { KEEP_X = 1, KEEP_A2 = 2, RES_X = 4 };                  // epilogue: also write fp32 to Xs / bf16 to A2; residual from Xs
+enum { ASRC_GLOBAL = 0, ASRC_X = 1, ASRC_A2 = 2, ASRC_AS = 3 };   // where the A operand comes from (AS: already in As, left by KEEP_AS)
+enum { KEEP_X = 1, KEEP_A2 = 2, RES_X = 4, KEEP_AS = 8 };     // epilogue: also write fp32 to Xs / bf16 to A2 / bf16 to As; residual from Xs
 struct RowSmem { bf16* As; float* Fs; float* Gs; float* Xs; bf16* A2; int ldf; int ldx; int lda2; };
 
 // (sequence, window) of row `row` of a tile whose first row is window t0 of sequence b0.  An integer division by a run-time
@@ -132,11 +136,13 @@ __device__ __forceinline__ ColPos col_pos(int n, int HD, int DKP) {
     return cp;
 }
 
-template <int EPI, bool LNPRO, int ASRC, int KEEP>
+template <int EPI, bool LNPRO, int ASRC, int KEEP, bool CHUNKS = false>     // CHUNKS: K-chunked A staging (RowGemmParams::kchunk)
 __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowSmem& sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int KP = p.KP, NP = p.NP, K = p.K, M = p.M;
-    const int lda_s = (ASRC == ASRC_A2) ? sm.lda2 : KP + 8;    // A tile row stride (bf16 elements)
+    // K-chunked staging: kc columns of the A tile in LDS at a time (kc == KP: all of it, the usual case)
+    const int kc = (CHUNKS && p.kchunk > 0 && p.kchunk < KP) ? p.kchunk : KP;
+    const int lda_s = (ASRC == ASRC_A2) ? sm.lda2 : kc + 8;    // A tile row stride (bf16 elements)
     const int ldf = sm.ldf;
     bf16* As = (ASRC == ASRC_A2) ? sm.A2 : sm.As;
     float* Fs = sm.Fs;
@@ -168,8 +174,20 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     if (wave * MMT_WCOLS < NP) w_prime(wave * MMT_WCOLS);
 
     // ------------------------------------------------------------------ 1. A tile -> LDS (bf16)
-    if (ASRC == ASRC_A2) {
-        // the previous stage left the bf16 tile in A2 (and ended on a barrier)
+    auto stage_a16 = [&](int k0) {                              // columns [k0, k0 + kc) of a bf16 A matrix in global memory
+        const bf16* A = static_cast<const bf16*>(p.A);
+        for (int row = tid >> 3; row < ROWS; row += MMT_RTHREADS / 8)               // 8 lanes x 16 bytes along a row
+        for (int c = (tid & 7) * 8; c < kc; c += 64) {
+            const int m = m0 + row;
+            bf16x8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (bf16)0.f;
+            if (m < M && k0 + c < K) v = *reinterpret_cast<const bf16x8*>(A + (size_t)m * p.lda + k0 + c);
+            *reinterpret_cast<bf16x8*>(As + row * lda_s + c) = v;
+        }
+    };
+    if (ASRC == ASRC_A2 || ASRC == ASRC_AS) {
+        // the previous stage left the bf16 tile in A2 / As (and ended on a barrier)
     } else if (LNPRO) {
         if (ASRC == ASRC_GLOBAL) {
             const float* A = static_cast<const float*>(p.A);
@@ -234,16 +252,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             *reinterpret_cast<bf16x4*>(As + row * lda_s + c) = o;
         }
     } else if (p.a_bf16) {
-        const bf16* A = static_cast<const bf16*>(p.A);
-        for (int row = tid >> 3; row < ROWS; row += MMT_RTHREADS / 8)               // 8 lanes x 16 bytes along a row
-        for (int c = (tid & 7) * 8; c < KP; c += 64) {
-            const int m = m0 + row;
-            bf16x8 v;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (bf16)0.f;
-            if (m < M && c < K) v = *reinterpret_cast<const bf16x8*>(A + (size_t)m * p.lda + c);
-            *reinterpret_cast<bf16x8*>(As + row * lda_s + c) = v;
-        }
+        stage_a16(0);
     } else {
         const float* A = static_cast<const float*>(p.A);
         for (int row = tid >> 4; row < ROWS; row += MMT_RTHREADS / 16)
@@ -280,7 +289,8 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     // ------------------------------------------------------------------ 2. chunks of 128 columns
     for (int n0 = 0; n0 < NP; n0 += 128) {
         const int nb = n0 + wave * MMT_WCOLS;
-        if (nb < NP) {
+        const bool active = nb < NP;                       // wave-uniform; with K-chunked staging idle waves still take part in the barriers
+        if (CHUNKS || active) {
             f32x4 acc[MT][MMT_WNT];
 #pragma unroll
             for (int a = 0; a < MT; ++a)
@@ -288,39 +298,45 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                 for (int b = 0; b < MMT_WNT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
             const bf16* arow0 = As + l15 * lda_s + 8 * lq;
             const bf16* arow1 = arow0 + 16 * lda_s;
+            if (CHUNKS && kc < KP && n0 > 0) { __syncthreads(); stage_a16(0); __syncthreads(); }      // K-chunked: back to the first chunk
             for (int kb0 = 0; kb0 < KP; kb0 += 64 * PFD) {
 #pragma unroll
                 for (int j = 0; j < PFD; ++j) {
                     const int kb = kb0 + 64 * j;
                     if (kb >= KP) break;                          // wave-uniform
-                    const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(arow0 + kb);
-                    const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(arow0 + kb + 32);
+                    if (CHUNKS && kc < KP && kb > 0 && (kb & (kc - 1)) == 0) { __syncthreads(); stage_a16(kb); __syncthreads(); }
+                    if (CHUNKS && !active) continue;
+                    const int ka = (CHUNKS && kc < KP) ? (kb & (kc - 1)) : kb;
+                    const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(arow0 + ka);
+                    const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(arow0 + ka + 32);
 #pragma unroll
                     for (int b = 0; b < MMT_WNT; ++b) acc[0][b] = mfma16(a00, wf[j][0][b], acc[0][b]);
                     if (MT == 2) {
-                        const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(arow1 + kb);
+                        const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(arow1 + ka);
 #pragma unroll
                         for (int b = 0; b < MMT_WNT; ++b) acc[MT - 1][b] = mfma16(a01, wf[j][0][b], acc[MT - 1][b]);
                     }
 #pragma unroll
                     for (int b = 0; b < MMT_WNT; ++b) acc[0][b] = mfma16(a10, wf[j][1][b], acc[0][b]);
                     if (MT == 2) {
-                        const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(arow1 + kb + 32);
+                        const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(arow1 + ka + 32);
 #pragma unroll
                         for (int b = 0; b < MMT_WNT; ++b) acc[MT - 1][b] = mfma16(a11, wf[j][1][b], acc[MT - 1][b]);
                     }
                     if (kb + 64 * PFD < KP) w_load(j, nb, kb + 64 * PFD);        // the slot just consumed takes the block PFD ahead
                 }
             }
-            if (nb + 128 < NP) w_prime(nb + 128);                 // next chunk's first blocks travel behind this chunk's epilogue
-            const int cbase = ((EPI == EPI_LNBWD) ? nb : wave * MMT_WCOLS) + l15;
+            if (active) {
+                if (nb + 128 < NP) w_prime(nb + 128);             // next chunk's first blocks travel behind this chunk's epilogue
+                const int cbase = ((EPI == EPI_LNBWD) ? nb : wave * MMT_WCOLS) + l15;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < MMT_WNT; ++nt)
+                    for (int nt = 0; nt < MMT_WNT; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        Fs[(mt * 16 + 4 * lq + r) * ldf + cbase + nt * 16] = acc[mt][nt][r];
+                        for (int r = 0; r < 4; ++r)
+                            Fs[(mt * 16 + 4 * lq + r) * ldf + cbase + nt * 16] = acc[mt][nt][r];
+            }
         }
         if (EPI == EPI_LNBWD) { PHASE(2); continue; }
         __syncthreads();
@@ -518,34 +534,52 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                     s1 += g[i];
                     s2 += g[i] * xh[i];
                 }
-                f32x4 gx;
+                if (!p.no_gs) {
+                    f32x4 gx;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) gx[i] = dy[i] * xh[i];
-                *reinterpret_cast<f32x4*>(gr + c) = gx;
+                    for (int i = 0; i < 4; ++i) gx[i] = dy[i] * xh[i];
+                    *reinterpret_cast<f32x4*>(gr + c) = gx;
+                }
             } else {
                 *reinterpret_cast<f32x4*>(cr + c) = g;
-                *reinterpret_cast<f32x4*>(gr + c) = g;
+                if (!p.no_gs) *reinterpret_cast<f32x4*>(gr + c) = g;
             }
         }
         s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
         s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
         if (TPR == 16) { s1 += __shfl_xor(s1, 8); s2 += __shfl_xor(s2, 8); }
-        if (m < M) {
-            const float sigma = 1.0f / rstd - p.eps;
+        {
+            const bool live = m < M;
+            const float sigma = live ? 1.0f / rstd - p.eps : 1.f;
             const float k1 = s1 / (float)d, k2 = s2 / ((float)(d - 1) * sigma);
-            for (int c = j * 4; c < d; c += 4 * TPR) {
-                f32x4 dy = *reinterpret_cast<const f32x4*>(cr + c);
-                f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + c);
-                f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_a + c);
-                f32x4 o;
+            for (int c = j * 4; c < ((KEEP & KEEP_AS) ? NP : d); c += 4 * TPR) {
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                if (live && c < d) {
+                    f32x4 dy = *reinterpret_cast<const f32x4*>(cr + c);
+                    f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + c);
+                    f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_a + c);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float xh = (xv[i] - mean) * rstd;
-                    o[i] = rstd * (dy[i] * a[i] - k1) - k2 * xh;
+                    for (int i = 0; i < 4; ++i) {
+                        const float xh = (xv[i] - mean) * rstd;
+                        o[i] = rstd * (dy[i] * a[i] - k1) - k2 * xh;
+                    }
+                    if (p.dres) { f32x4 r = *reinterpret_cast<const f32x4*>(p.dres + (size_t)m * p.lddres + c); o += r; }
+                    *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + c) = o;
+                    if (KEEP & KEEP_X) *reinterpret_cast<f32x4*>(Xs + row * sm.ldx + c) = o;
                 }
-                if (p.dres) { f32x4 r = *reinterpret_cast<const f32x4*>(p.dres + (size_t)m * p.lddres + c); o += r; }
-                *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + c) = o;
-                if (KEEP & KEEP_X) *reinterpret_cast<f32x4*>(Xs + row * sm.ldx + c) = o;
+                if (KEEP & KEEP_AS) {        // the next stage's A tile: bf16 of the (dropped) gradient, zero in the pads and in rows >= M
+                    if (p.next_drop.thr16 && live && c < d) {
+#pragma unroll
+                        for (int i = 0; i < 4; i += 2) {
+                            const uint32_t w = drop_pair(p.next_drop, (uint64_t)m * NP + c + i);
+                            o[i] = drop_lo(p.next_drop, w, o[i]); o[i + 1] = drop_hi(p.next_drop, w, o[i + 1]);
+                        }
+                    }
+                    bf16x4 o16;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o16[i] = (bf16)o[i];
+                    *reinterpret_cast<bf16x4*>(sm.As + row * p.next_lda + c) = o16;
+                }
             }
         }
         }
@@ -553,8 +587,22 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         if (p.colpart) {
             for (int c = tid; c < NP; c += MMT_RTHREADS) {
                 float sb = 0.f, sa = 0.f;
+                if (!p.no_gs) {
 #pragma unroll 8
-                for (int r = 0; r < MMT_ROWS; ++r) { sb += Fs[r * ldf + c]; sa += Gs[r * (NP + 4) + c]; }
+                    for (int r = 0; r < MMT_ROWS; ++r) { sb += Fs[r * ldf + c]; sa += Gs[r * (NP + 4) + c]; }
+                } else {
+                    // no second fp32 tile (it halves the workgroups per CU at d_model = 256): x-hat again from x (an L2 hit, just read
+                    // by the row pass) with the same expression, so the sums are bit-identical to the stored form
+                    const int nr = (M - m0 < MMT_ROWS) ? M - m0 : MMT_ROWS;
+                    for (int r = 0; r < nr; ++r) {
+                        const float dyv = Fs[r * ldf + c];
+                        sb += dyv;
+                        if (c < d) {
+                            const float mr = p.st[2 * (size_t)(m0 + r)], rr = p.st[2 * (size_t)(m0 + r) + 1];
+                            sa += dyv * ((p.x[(size_t)(m0 + r) * p.ldx + c] - mr) * rr);
+                        }
+                    }
+                }
                 float* dst = p.colpart + (size_t)blockIdx.x * 2 * NP;
                 dst[c] = sb; dst[NP + c] = sa;
             }
@@ -577,16 +625,16 @@ __device__ __forceinline__ void warm_weights(const bf16* W, int NP, int KP) {
 }
 
 // ---- single stage ------------------------------------------------------------------------------
-template <int EPI, bool LNPRO>
+template <int EPI, bool LNPRO, bool CHUNKS = false>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void rowgemm_kernel(const RowGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     RowSmem sm;
     sm.As = reinterpret_cast<bf16*>(smem);
-    sm.Fs = reinterpret_cast<float*>(smem + (size_t)MMT_ROWS * (p.KP + 8) * 2);
+    sm.Fs = reinterpret_cast<float*>(smem + (size_t)MMT_ROWS * ((p.kchunk > 0 && p.kchunk < p.KP ? p.kchunk : p.KP) + 8) * 2);
     sm.ldf = rowgemm_fw(EPI, LNPRO, p.KP, p.NP) + 4;
     sm.Gs = sm.Fs + (size_t)MMT_ROWS * sm.ldf;
     sm.Xs = nullptr; sm.A2 = nullptr; sm.ldx = 0; sm.lda2 = 0;
-    rowgemm_stage<EPI, LNPRO, ASRC_GLOBAL, 0>(p, sm);
+    rowgemm_stage<EPI, LNPRO, ASRC_GLOBAL, 0, CHUNKS>(p, sm);
 }
 
 // ---- chained stages ------------------------------------------------------------------------------
@@ -638,13 +686,13 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
 
 // Backward, from the layer-output gradient dx2 down to the attention core's operands:
 //     dh  = (drop'(dx2) W2) * relu'(hid) * drop'          (dh kept in LDS as the next A tile; dx2^T, dh^T emitted for dW)
-//     dx1 = dx2 + LN2bwd(dh W1)                            (kept in LDS)
+//     dx1 = dx2 + LN2bwd(dh W1)                            (drop'(dx1) kept in LDS as the next A tile)
 //     dO  = drop'(dx1) Wo  -> fragment layouts + delta     (dx1^T emitted for dW)
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_pre_attn_bwd_kernel(const RowChain3 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const RowSmem sm = rowchain_carve(smem, ch, true);
+    const RowSmem sm = rowchain_carve(smem, ch, !ch.b.no_gs);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
     rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_A2>(ch.a, sm);
-    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_X>(ch.b, sm);
-    rowgemm_stage<EPI_FRAG, false, ASRC_X, 0>(ch.c, sm);
+    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS>(ch.b, sm);          // dx1 -> global (fp32) and, as the next A tile, LDS (bf16)
+    rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0>(ch.c, sm);
 }

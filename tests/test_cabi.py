@@ -39,7 +39,8 @@ def test_shape_queries_and_validation():
     assert lib.mmt_encoder_workspace_bytes(4, 50, 256, 2, 128, 2) == 0            # d_k = 128 unsupported
     assert b"d_k" in lib.mmt_last_error()
     assert lib.mmt_encoder_workspace_bytes(4, 50, 256, 4, 128, 2) > 0             # d_k = 64
-    assert lib.mmt_encoder_workspace_bytes(4, 50, 512, 8, 128, 2) == 0            # window tile does not fit the LDS
+    assert lib.mmt_encoder_workspace_bytes(4, 50, 512, 8, 128, 2) > 0             # d_model = 512 fits (K-chunked staging, one fp32 tile)
+    assert lib.mmt_encoder_workspace_bytes(4, 50, 1024, 16, 128, 2) == 0          # window tile does not fit the LDS
     assert b"LDS" in lib.mmt_last_error()
     rc = lib.mmt_encoder_forward(None, None, None, None, None, 0, 4, 50, 128, 8, 128, 2, 1e-6, 0.0, 0, None)
     assert rc == 1 and b"null" in lib.mmt_last_error()

@@ -70,6 +70,13 @@ def test_head_size_64(dev):
     _check_encoder(dev, 192, 4, 1, 2, 33, [33, 9], "edge:dk48")
 
 
+def test_wide_model_512(dev):
+    """d_model = 512 (h = 8, d_k = 64): the widest window tile the LDS takes — K-chunked staging of the 1536-wide dQKV tile, column
+    sums of the LayerNorm backward without the second fp32 tile; forward and every gradient vs the oracle"""
+    _check_encoder(dev, 512, 8, 1, 2, 40, [40, 17], "edge:d512")
+    _check_encoder(dev, 320, 8, 2, 2, 37, [37, 37], "edge:d320")
+
+
 def test_long_sequence_eval_and_dropout_limit(dev):
     """T = 2500 runs in eval mode; train-mode attention dropout is limited to T <= 4096 (24-bit pair index) and says so"""
     from multimodal_transformer_amd import multiTransformer as MT
