@@ -519,6 +519,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         float* gr = Gs + row * (NP + 4);
         float mean = 0.f, rstd = 0.f;
         if (m < M) { mean = p.st[2 * (size_t)m]; rstd = p.st[2 * (size_t)m + 1]; }
+        if (p.no_gs && j == 0) { cr[NP] = mean; cr[NP + 1] = rstd; }        // pad columns of the tile row (ldf = NP + 4): for the column pass
         {
         float s1 = 0.f, s2 = 0.f;
         for (int c = j * 4; c < NP; c += 4 * TPR) {
@@ -592,14 +593,18 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                     for (int r = 0; r < MMT_ROWS; ++r) { sb += Fs[r * ldf + c]; sa += Gs[r * (NP + 4) + c]; }
                 } else {
                     // no second fp32 tile (it halves the workgroups per CU at d_model = 256): x-hat again from x (an L2 hit, just read
-                    // by the row pass) with the same expression, so the sums are bit-identical to the stored form
-                    const int nr = (M - m0 < MMT_ROWS) ? M - m0 : MMT_ROWS;
-                    for (int r = 0; r < nr; ++r) {
-                        const float dyv = Fs[r * ldf + c];
-                        sb += dyv;
-                        if (c < d) {
-                            const float mr = p.st[2 * (size_t)(m0 + r)], rr = p.st[2 * (size_t)(m0 + r) + 1];
-                            sa += dyv * ((p.x[(size_t)(m0 + r) * p.ldx + c] - mr) * rr);
+                    // by the row pass) with the same expression, so the sums are bit-identical to the stored form.  Eight rows' loads
+                    // in flight at a time; the rows' (mean, 1/std) were parked in the tile's pad columns by the row pass.
+                    for (int r0 = 0; r0 < MMT_ROWS; r0 += 8) {
+                        float xv[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) xv[i] = (m0 + r0 + i < M && c < d) ? p.x[(size_t)(m0 + r0 + i) * p.ldx + c] : 0.f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float* fr = Fs + (r0 + i) * ldf;
+                            const float dyv = fr[c];
+                            sb += dyv;
+                            sa += dyv * ((xv[i] - fr[NP]) * fr[NP + 1]);
                         }
                     }
                 }
