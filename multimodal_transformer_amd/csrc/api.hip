@@ -124,7 +124,7 @@ static int make_dims(EncDims& D, int B, int T, int d, int h, int f, int N) {
         const bool no_gs = L.DP > 128;
         const size_t bwd_chain = (size_t)MMT_ROWS * ((kmax + 8) * 2 + (fw + 4) * 4 * (no_gs ? 1 : 2) + (L.FP + 8) * 2);
         const size_t fwd_chain = (size_t)MMT_ROWS * ((kmax + 8) * 2 + (128 + 4) * 4 + (L.DP + 4) * 4 + (L.FP + 8) * 2);
-        const size_t bwd_qkv = rowgemm_lds_bytes(EPI_LNBWD, false, L.NQ, L.DP, L.NQ > 512 ? 512 : 0, no_gs);
+        const size_t bwd_qkv = rowgemm_lds_bytes(EPI_LNBWD, false, L.NQ, L.DP, L.NQ > 512 ? 512 : 0, no_gs || L.NQ > 512);
         const size_t worst = std::max(std::max(bwd_chain, fwd_chain), bwd_qkv);
         if (worst > 160 * 1024)
             return fail(MMT_EUNSUPPORTED, "d_model %d / d_ff %d: a %d-window tile of the row kernels needs %zu B of LDS (160 KB per CU)",
@@ -222,22 +222,23 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
 }
 
 // ------------------------------------------------------------------------------------ launch helpers
-template <int EPI, bool LN, bool CHUNKS = false>
+template <int EPI, bool LN, bool WIDE = false>
 static int launch_rowgemm(const RowGemmParams& p, hipStream_t st, int site = S_OTHER) {
-    if (!CHUNKS && p.kchunk > 0 && p.kchunk < p.KP) return launch_rowgemm<EPI, LN, true>(p, st, site);     // K-chunked staging: its own instance
+    if (EPI == EPI_LNBWD && !WIDE && p.no_gs) return launch_rowgemm<EPI_LNBWD, false, true>(p, st, site);      // d_model > 128: its own instance
+    if (!WIDE && (p.no_gs || p.kchunk)) return fail(MMT_EINVAL, "K-chunked staging / single-tile column sums exist for the LayerNorm-backward kernel only");
     const size_t lds = rowgemm_lds_bytes(EPI, LN, p.KP, p.NP, p.kchunk, p.no_gs != 0);
     if (lds > 160 * 1024) return fail(MMT_EUNSUPPORTED, "row GEMM tile needs %zu B of LDS (K=%d, N=%d)", lds, p.K, p.N);
-    if (CHUNKS && (!p.a_bf16 || (p.kchunk & (p.kchunk - 1)) || p.kchunk < 64 || p.A_out))
+    if (WIDE && p.kchunk && (!p.a_bf16 || (p.kchunk & (p.kchunk - 1)) || p.kchunk < 64 || p.A_out))
         return fail(MMT_EINVAL, "K-chunked staging needs a bf16 A matrix, a power-of-two chunk >= 64 and no A copy");
     static size_t configured = 0;           // per instantiation
     if (lds > configured) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<EPI, LN, CHUNKS>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<EPI, LN, WIDE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = 160 * 1024;
     }
     const int grid = (p.M + MMT_ROWS - 1) / MMT_ROWS;
     ProfScope prof(site, st);
-    hipLaunchKernelGGL((rowgemm_kernel<EPI, LN, CHUNKS>), dim3(grid), dim3(MMT_RTHREADS), lds, st, p);
+    hipLaunchKernelGGL((rowgemm_kernel<EPI, LN, WIDE>), dim3(grid), dim3(MMT_RTHREADS), lds, st, p);
     LAUNCH_CHECK("rowgemm_kernel");
     return MMT_OK;
 }
@@ -581,7 +582,9 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
                 p.T = T; p.Tp = D.Tp; p.h = h; p.DKP = L.DKP; p.nwhich = 1;
                 p.ctx = w.ctx; p.ldctx = L.HDP; p.delta = W.delta; }
             ch.ldx = 0; ch.lda2 = L.FP + 8;                        // no fp32 tile kept between the stages
-            if ((rc = launch_rowchain(encoder_pre_attn_bwd_kernel, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st))) return rc;
+            if (ch.b.no_gs) rc = launch_rowchain(encoder_pre_attn_bwd_kernel<true>, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st);
+            else rc = launch_rowchain(encoder_pre_attn_bwd_kernel<false>, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st);
+            if (rc) return rc;
         }
         if ((rc = launch_attn_bwd(L.DKP, w.QR, w.KR, w.VR, W.dOR, w.lse, W.delta, mask,
                                   w.dqkv, D, st, make_drop(dropout_p, seed, 4 * l + 0), w.maskQ, w.maskK))) return rc;
@@ -593,8 +596,8 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             p.W = wp + L.pWqkvT();
             p.x = xin; p.ldx = d; p.st = w.stats1; p.ln_a = P + L.oln(0); p.eps = eps; p.d_real = d;
             p.dres = other; p.lddres = d; p.out_f32 = dxin; p.ldo = d; p.colpart = w.lnpart1;
-            p.no_gs = L.DP > 128;
             p.kchunk = (L.NQ > 512) ? 512 : 0;                     // d_model = 256: K = 768; half of the A tile in LDS at a time
+            p.no_gs = (L.DP > 128) || p.kchunk;                    // (both live in the WIDE instance of the kernel)
             if ((rc = launch_rowgemm<EPI_LNBWD, false>(p, st, S_BWD_QKV_LN1))) return rc;
         }
         // weight-gradient jobs of this layer (run later, all layers in one launch)

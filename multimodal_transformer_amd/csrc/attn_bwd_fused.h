@@ -7,7 +7,8 @@
 // (attn_bwd_dkv_kernel's d_k = 16 trick); all waves sweep the query tiles together, sharing the staged Q / dO / L / delta tile like
 // the 4-wave kernels do.  Per query tile each wave also forms its 32-key share of dQ^T = K^T dS^T:
 //   * dS sits in the accumulator layout with the key on the lane; the dQ product contracts over keys, so dS goes through a
-//     wave-private LDS patch [32 queries][32 keys] bf16 (16 ds_write_b16 + 2 ds_read_b128 per lane) to become a B operand;
+//     wave-private LDS patch to become a B operand: each lane writes its key's 16 packed values as they lie in its registers (two
+//     ds_write_b128; round 1 scattered them with 16 ds_write_b16) and the query-major fragments come back through transposing reads;
 //   * every operand exists in memory in ONE layout, the R fragment layout (window-major).  The products that contract over windows
 //     (dV^T += dO^T P, dK^T += Q'^T dS over the queries, dQ^T = K^T dS^T over the keys) take their A fragments out of the staged
 //     tiles with transposing LDS reads (common.h tr_frag2); round 1/2 staged a second, transposed copy of Q and dO (2 KB of the
@@ -26,7 +27,7 @@
 
 #define MMT_FUSED_NW 16
 #define MMT_FUSED_THREADS (MMT_FUSED_NW * 64)
-#define MMT_FUSED_PATCH_LD 40                               // bf16 per patch row: 32 keys + 8 pad (80-byte rows: conflict-free b128 reads)
+#define MMT_FUSED_PATCH_LD 40                               // bf16 per patch row (one key): 2 halves x 16 accumulator slots + 8 pad (80-byte rows: conflict-free b128 writes)
 #define MMT_FUSED_PART_LD 68                                // floats per partial register row: 64 lanes + 4 pad
 #define MMT_FUSED_REGION_BYTES 2560                         // max(32 * 40 * 2, 8 * 68 * 4)
 #define MMT_FUSED_RT_PIECES (2 * MMT_TR_OCT)                // an R tile of d_k = 16 in LDS: two 8-feature groups, 576 bytes apart (attn.h TileStager)
@@ -251,21 +252,24 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
                 const bf16x8 pds = pack8(dp, s2);
                 acc = mfma32(tr_frag2(ado + 128 * s2, ado + 128 * s2 + 64), pack8(s, s2), acc);
                 acc = mfma32(tr_frag2(aq + 128 * s2, aq + 128 * s2 + 64), pds, acc);
-#pragma unroll
-                for (int j = 0; j < 8; ++j)             // register 8*s2 + j holds query row acc32_row(8*s2 + j, hh) of this lane's key
-                    patch[acc32_row(8 * s2 + j, hh) * MMT_FUSED_PATCH_LD + r] = pds[j];
+                // patch row = this lane's key; slots [hh][8 s2 + j] = query acc32_row(8 s2 + j, hh): every aligned group of 4 slots
+                // is 4 consecutive queries, the unit a transposing read hands out
+                *reinterpret_cast<bf16x8*>(patch + r * MMT_FUSED_PATCH_LD + 16 * hh + 8 * s2) = pds;
             }
             FB_STAMP(2);                                // packs, dV/dK products, patch writes
             // dQ^T share of this key tile: K^T (features x keys) times dS^T (keys x queries).  K^T fragments by transposing reads of
             // the own K tile: slot j <-> key 16 s2 + 8 hh + j, the patch's column order; lanes r >= 16 would produce the padding
             // feature rows, which nobody reads: they supply (and receive) the same as lanes r - 16
             const bf16* const ak = reinterpret_cast<const bf16*>(kvl0 + wave * (2 * RT * 16)) + toff + 64 * hh;
+            // dS^T fragments: this lane supplies key tq of a 4-key block and the 4 queries 16 up + 4 tpp .. + 3 (patch slots
+            // [tpp & 1][4 (2 up + (tpp >> 1)) ..]) and receives its own query r for those keys; slot j <-> key 16 s2 + 8 hh + j
+            const bf16* const pb = patch + (8 * hh + tq) * MMT_FUSED_PATCH_LD + 16 * (tpp & 1) + 4 * (2 * (int)up + (tpp >> 1));
             f32x16 dqp;
 #pragma unroll
             for (int j = 0; j < 16; ++j) dqp[j] = 0.f;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(patch + r * MMT_FUSED_PATCH_LD + 16 * s2 + 8 * hh);
+                const bf16x8 bfrag = tr_frag2(pb + 16 * MMT_FUSED_PATCH_LD * s2, pb + 16 * MMT_FUSED_PATCH_LD * s2 + 4 * MMT_FUSED_PATCH_LD);
                 dqp = mfma32(tr_frag2(ak + 128 * s2, ak + 128 * s2 + 32), bfrag, dqp);
             }
             float* const part = reinterpret_cast<float*>(region);

@@ -136,12 +136,15 @@ __device__ __forceinline__ ColPos col_pos(int n, int HD, int DKP) {
     return cp;
 }
 
-template <int EPI, bool LNPRO, int ASRC, int KEEP, bool CHUNKS = false>     // CHUNKS: K-chunked A staging (RowGemmParams::kchunk)
+// WIDE: the d_model > 128 variant of a LayerNorm-backward stage — K-chunked A staging (RowGemmParams::kchunk) and column sums without the
+// second fp32 tile (RowGemmParams::no_gs, which the host sets to match).  Its own instantiation, so that the d_model <= 128 kernels
+// carry neither the extra barriers nor the registers of the batched re-reads.
+template <int EPI, bool LNPRO, int ASRC, int KEEP, bool WIDE = false>
 __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowSmem& sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int KP = p.KP, NP = p.NP, K = p.K, M = p.M;
     // K-chunked staging: kc columns of the A tile in LDS at a time (kc == KP: all of it, the usual case)
-    const int kc = (CHUNKS && p.kchunk > 0 && p.kchunk < KP) ? p.kchunk : KP;
+    const int kc = (WIDE && p.kchunk > 0 && p.kchunk < KP) ? p.kchunk : KP;
     const int lda_s = (ASRC == ASRC_A2) ? sm.lda2 : kc + 8;    // A tile row stride (bf16 elements)
     const int ldf = sm.ldf;
     bf16* As = (ASRC == ASRC_A2) ? sm.A2 : sm.As;
@@ -157,7 +160,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     // first chunk go in flight NOW: their latency overlaps the A-tile staging.  The stand-alone LayerNorm-backward instance
     // (bwd_qkv: K = 3 h d_k, six k-blocks at d_model = 128, 58 VGPRs) keeps six blocks in flight — with two, four L2 round trips
     // per tile were exposed; the chained kernels sit at the 128-VGPR cap and keep two.
-    constexpr int PFD = (EPI == EPI_LNBWD && ASRC == ASRC_GLOBAL && KEEP == 0) ? 6 : 2;
+    constexpr int PFD = (EPI == EPI_LNBWD && ASRC == ASRC_GLOBAL && KEEP == 0) ? (WIDE ? 4 : 6) : 2;
     bf16x8 wf[PFD][2][MMT_WNT];                                   // [slot][k half: +0 / +32][16-column tile of the wave]
     auto w_load = [&](int slot, int nb, int kb) {                 // slot and the guard are compile-time / wave-uniform
         const bf16* wr = p.W + (size_t)(nb + l15) * KP + 8 * lq + kb;
@@ -290,7 +293,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     for (int n0 = 0; n0 < NP; n0 += 128) {
         const int nb = n0 + wave * MMT_WCOLS;
         const bool active = nb < NP;                       // wave-uniform; with K-chunked staging idle waves still take part in the barriers
-        if (CHUNKS || active) {
+        if (WIDE || active) {
             f32x4 acc[MT][MMT_WNT];
 #pragma unroll
             for (int a = 0; a < MT; ++a)
@@ -298,15 +301,15 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                 for (int b = 0; b < MMT_WNT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
             const bf16* arow0 = As + l15 * lda_s + 8 * lq;
             const bf16* arow1 = arow0 + 16 * lda_s;
-            if (CHUNKS && kc < KP && n0 > 0) { __syncthreads(); stage_a16(0); __syncthreads(); }      // K-chunked: back to the first chunk
+            if (WIDE && kc < KP && n0 > 0) { __syncthreads(); stage_a16(0); __syncthreads(); }      // K-chunked: back to the first chunk
             for (int kb0 = 0; kb0 < KP; kb0 += 64 * PFD) {
 #pragma unroll
                 for (int j = 0; j < PFD; ++j) {
                     const int kb = kb0 + 64 * j;
                     if (kb >= KP) break;                          // wave-uniform
-                    if (CHUNKS && kc < KP && kb > 0 && (kb & (kc - 1)) == 0) { __syncthreads(); stage_a16(kb); __syncthreads(); }
-                    if (CHUNKS && !active) continue;
-                    const int ka = (CHUNKS && kc < KP) ? (kb & (kc - 1)) : kb;
+                    if (WIDE && kc < KP && kb > 0 && (kb & (kc - 1)) == 0) { __syncthreads(); stage_a16(kb); __syncthreads(); }
+                    if (WIDE && !active) continue;
+                    const int ka = (WIDE && kc < KP) ? (kb & (kc - 1)) : kb;
                     const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(arow0 + ka);
                     const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(arow0 + ka + 32);
 #pragma unroll
@@ -519,7 +522,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         float* gr = Gs + row * (NP + 4);
         float mean = 0.f, rstd = 0.f;
         if (m < M) { mean = p.st[2 * (size_t)m]; rstd = p.st[2 * (size_t)m + 1]; }
-        if (p.no_gs && j == 0) { cr[NP] = mean; cr[NP + 1] = rstd; }        // pad columns of the tile row (ldf = NP + 4): for the column pass
+        if (WIDE && j == 0) { cr[NP] = mean; cr[NP + 1] = rstd; }        // pad columns of the tile row (ldf = NP + 4): for the column pass
         {
         float s1 = 0.f, s2 = 0.f;
         for (int c = j * 4; c < NP; c += 4 * TPR) {
@@ -535,7 +538,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                     s1 += g[i];
                     s2 += g[i] * xh[i];
                 }
-                if (!p.no_gs) {
+                if (!WIDE) {
                     f32x4 gx;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) gx[i] = dy[i] * xh[i];
@@ -543,7 +546,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                 }
             } else {
                 *reinterpret_cast<f32x4*>(cr + c) = g;
-                if (!p.no_gs) *reinterpret_cast<f32x4*>(gr + c) = g;
+                if (!WIDE) *reinterpret_cast<f32x4*>(gr + c) = g;
             }
         }
         s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
@@ -588,19 +591,21 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         if (p.colpart) {
             for (int c = tid; c < NP; c += MMT_RTHREADS) {
                 float sb = 0.f, sa = 0.f;
-                if (!p.no_gs) {
+                if (!WIDE) {
 #pragma unroll 8
                     for (int r = 0; r < MMT_ROWS; ++r) { sb += Fs[r * ldf + c]; sa += Gs[r * (NP + 4) + c]; }
                 } else {
                     // no second fp32 tile (it halves the workgroups per CU at d_model = 256): x-hat again from x (an L2 hit, just read
-                    // by the row pass) with the same expression, so the sums are bit-identical to the stored form.  Eight rows' loads
+                    // by the row pass) with the same expression, so the sums are bit-identical to the stored form.  Four rows' loads
                     // in flight at a time; the rows' (mean, 1/std) were parked in the tile's pad columns by the row pass.
-                    for (int r0 = 0; r0 < MMT_ROWS; r0 += 8) {
-                        float xv[8];
+                    // (rows >= M: dy = 0 and the parked statistics are 0, so any finite x will do: the last valid row's)
+                    const float* xc = p.x + (c < d ? c : 0);
+                    for (int r0 = 0; r0 < MMT_ROWS; r0 += 4) {
+                        float xv[4];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) xv[i] = (m0 + r0 + i < M && c < d) ? p.x[(size_t)(m0 + r0 + i) * p.ldx + c] : 0.f;
+                        for (int i = 0; i < 4; ++i) { const int mr = m0 + r0 + i; xv[i] = xc[(size_t)(mr < M ? mr : M - 1) * p.ldx]; }
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
+                        for (int i = 0; i < 4; ++i) {
                             const float* fr = Fs + (r0 + i) * ldf;
                             const float dyv = fr[c];
                             sb += dyv;
@@ -630,7 +635,7 @@ __device__ __forceinline__ void warm_weights(const bf16* W, int NP, int KP) {
 }
 
 // ---- single stage ------------------------------------------------------------------------------
-template <int EPI, bool LNPRO, bool CHUNKS = false>
+template <int EPI, bool LNPRO, bool WIDE = false>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void rowgemm_kernel(const RowGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     RowSmem sm;
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
     sm.ldf = rowgemm_fw(EPI, LNPRO, p.KP, p.NP) + 4;
     sm.Gs = sm.Fs + (size_t)MMT_ROWS * sm.ldf;
     sm.Xs = nullptr; sm.A2 = nullptr; sm.ldx = 0; sm.lda2 = 0;
-    rowgemm_stage<EPI, LNPRO, ASRC_GLOBAL, 0, CHUNKS>(p, sm);
+    rowgemm_stage<EPI, LNPRO, ASRC_GLOBAL, 0, WIDE>(p, sm);
 }
 
 // ---- chained stages ------------------------------------------------------------------------------
@@ -693,11 +698,12 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
 //     dh  = (drop'(dx2) W2) * relu'(hid) * drop'          (dh kept in LDS as the next A tile; dx2^T, dh^T emitted for dW)
 //     dx1 = dx2 + LN2bwd(dh W1)                            (drop'(dx1) kept in LDS as the next A tile)
 //     dO  = drop'(dx1) Wo  -> fragment layouts + delta     (dx1^T emitted for dW)
+template <bool WIDE>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_pre_attn_bwd_kernel(const RowChain3 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const RowSmem sm = rowchain_carve(smem, ch, !ch.b.no_gs);
+    const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
     rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_A2>(ch.a, sm);
-    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS>(ch.b, sm);          // dx1 -> global (fp32) and, as the next A tile, LDS (bf16)
+    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, WIDE>(ch.b, sm);          // dx1 -> global (fp32) and, as the next A tile, LDS (bf16)
     rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0>(ch.c, sm);
 }
