@@ -32,11 +32,12 @@
 __device__ __forceinline__ void attn_keep_block(const DropCfg& dc, uint32_t blk, uint32_t (&W)[32]) {
     const uint32_t thr = dc.thr16;
     const int b0 = thr ? __builtin_ctz(thr) : 16;                 // wave-uniform
-    uint32_t x = drop_lin(dc.s0, blk * 512u) + (uint32_t)b0 * MMT_DROP_C1;   // word index blk*512 + key*16 + b  (< 2^24 for Tp <= 4096)
 #pragma unroll
     for (int key = 0; key < 32; ++key) W[key] = 0;                // the drop words D; threshold bits below b0 leave them 0
     // threshold bit outermost (a uniform, rolled loop), the 32 keys unrolled inside: 32 independent hash chains in flight (124 VGPRs,
-    // 4 waves per SIMD; 16 chains at 6 or 8 waves per SIMD measured no faster: the kernel is bound by integer issue, not latency)
+    // 4 waves per SIMD).  16 or 8 chains at 6 or 8 waves per SIMD (all 6144 waves of configs[3] resident at once) measured the same
+    // 58-60 us: the kernel is bound by the total integer instruction issue, not by latency, occupancy or its tail.
+    uint32_t x = drop_lin(dc.s0, blk * 512u) + (uint32_t)b0 * MMT_DROP_C1;   // word index blk*512 + key*16 + b  (< 2^24 for Tp <= 4096)
 #pragma unroll 1
     for (int b = b0; b < 16; ++b) {
         if ((thr >> b) & 1u) {
@@ -85,8 +86,10 @@ struct MaskGenParams {
     uint32_t s0[16], s1[16];               // stream keys of the layers' attention dropout (make_drop(p, seed, 4l+0))
 };
 
-// rows[x] = 32 bits over the lane index (x = the register-side index): writes the 64 lane words of one block, 8 x 16 bytes
-__device__ __forceinline__ void store_lane_block(uint16_t* dst, const uint32_t (&rows)[32]) {
+// rows[x] = 32 bits over the lane index (x = the register-side index): the 64 lane words of one block, 8 x 16 bytes, into this lane's
+// row of the wave's LDS patch
+#define MMT_MASK_LDS_ROW 72            // uint16 per patch row: 64 + 8 pad (144-byte rows: conflict-free 16-byte writes)
+__device__ __forceinline__ void park_lane_block(uint16_t* row, const uint32_t (&rows)[32]) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {          // piece c: lanes 8c .. 8c+7, i.e. half hh = c >> 2, lane-side index 8(c&3) .. +7
         u32x4_t v;
@@ -95,26 +98,61 @@ __device__ __forceinline__ void store_lane_block(uint16_t* dst, const uint32_t (
             const int l0 = 8 * (c & 3) + 2 * e, hh = c >> 2;
             v[e] = lane_word(rows[l0], hh) | (lane_word(rows[l0 + 1], hh) << 16);
         }
-        *reinterpret_cast<u32x4_t*>(dst + 8 * c) = v;
+        *reinterpret_cast<u32x4_t*>(row + 8 * c) = v;
     }
 }
 
-// one lane per 32x32 block; lanes of a wave walk the k tiles of one (bh, q tile) first: the LQ blocks of a wave are contiguous
+// One lane per 32x32 block; the lanes of a wave own 64 consecutive blocks in (bh, q tile, k tile) order.  A block is 128 bytes per
+// orientation, so lane-private stores would be 64 separate 16-byte writes per instruction (6.5 M partial-line transactions per launch
+// at configs[3]).  The wave parks its 64 blocks in LDS and writes them out with the lanes laid along memory (no change in the
+// kernel's own time — it is bound by integer issue — but whole lines reach the fabric): LQ blocks of a wave are contiguous (1 KB per store instruction), LK blocks are
+// written as whole 128-byte lines by 8 lanes each.
 __global__ __launch_bounds__(256, 4) void attn_mask_gen_kernel(const MaskGenParams P) {
-    const int layer = blockIdx.y;
-    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t per_bh = (size_t)P.nt * P.nt;
-    const int bh = (int)(g / per_bh);
-    if (bh >= P.nbh) return;
-    const int rem = (int)(g - (size_t)bh * per_bh), qt = rem / P.nt, kt = rem - qt * P.nt;
+    __shared__ __attribute__((aligned(16))) uint16_t patch[4][64 * MMT_MASK_LDS_ROW];
+    const int layer = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t g0 = (size_t)blockIdx.x * 256 + wave * 64;                 // first block of the wave
+    const size_t per_bh = (size_t)P.nt * P.nt, total = (size_t)P.nbh * per_bh;
+    if (g0 >= total) return;                                                // whole wave (no workgroup barrier below)
+    const size_t g = g0 + lane;
+    const bool live = g < total;
+    const size_t gc = live ? g : total - 1;
+    const int bh = (int)(gc / per_bh);
+    const int rem = (int)(gc - (size_t)bh * per_bh), qt = rem / P.nt, kt = rem - qt * P.nt;
     DropCfg base; base.thr16 = P.thr16; base.scale = 1.f; base.s0 = P.s0[layer]; base.s1 = P.s1[layer];
     const DropCfg dc = drop_substream(base, (uint32_t)bh);
     uint32_t W[32];
     attn_keep_block(dc, (uint32_t)(qt * P.nt + kt), W);                    // W[key] bit query
-    // key on the lane: lane-side index = key, its row = W[key] (bits over the queries = the register side)
-    store_lane_block(P.lk + (size_t)layer * P.layer_words + ((size_t)bh * per_bh + (size_t)kt * P.nt + qt) * 64, W);
+    uint16_t* const mine = patch[wave] + lane * MMT_MASK_LDS_ROW;
+    // flush role: in store instruction i this lane moves piece (lane & 7) of the wave's block 8 i + (lane >> 3)
+    const int fp = lane & 7;
+    const uint16_t* const from = patch[wave] + (lane >> 3) * MMT_MASK_LDS_ROW + 8 * fp;
+    // ---- LK: key on the lane: lane-side index = key, its row = W[key] (bits over the queries = the register side)
+    park_lane_block(mine, W);
+    {
+        // (bh, q tile, k tile) of block lane >> 3, then + 8 blocks per instruction
+        size_t gb = g0 + (lane >> 3);
+        int bb = (int)((gb < total ? gb : total - 1) / per_bh);
+        int rb = (int)((gb < total ? gb : total - 1) - (size_t)bb * per_bh), qb = rb / P.nt, kb = rb - qb * P.nt;
+        uint16_t* const lk = P.lk + (size_t)layer * P.layer_words;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(from + 8 * i * MMT_MASK_LDS_ROW);
+            if (gb < total) *reinterpret_cast<u32x4_t*>(lk + ((size_t)bb * per_bh + (size_t)kb * P.nt + qb) * 64 + 8 * fp) = v;
+            gb += 8; kb += 8;
+            while (kb >= P.nt) { kb -= P.nt; if (++qb == P.nt) { qb = 0; ++bb; } }
+        }
+    }
     transpose32(W);                                                        // W[query] bit key
-    store_lane_block(P.lq + (size_t)layer * P.layer_words + ((size_t)bh * per_bh + (size_t)qt * P.nt + kt) * 64, W);
+    // ---- LQ: block index == g: the wave's 64 blocks are contiguous in memory
+    park_lane_block(mine, W);              // (same wave wrote and read the patch: program order is enough, no barrier)
+    {
+        uint16_t* const lq = P.lq + (size_t)layer * P.layer_words + g0 * 64;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(from + 8 * i * MMT_MASK_LDS_ROW);
+            if (g0 + 8 * i + (lane >> 3) < total) *reinterpret_cast<u32x4_t*>(lq + (size_t)i * 512 + lane * 8) = v;
+        }
+    }
 }
 
 __host__ inline size_t attn_mask_layer_words(int nbh, int nt) { return (size_t)nbh * nt * nt * 64; }      // uint16 words per layer and orientation
