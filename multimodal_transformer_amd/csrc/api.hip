@@ -533,12 +533,7 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
     const float* x_last = (D.N > 0) ? W.lw[D.N - 1].xout : x;
     float* cur = (D.N > 0) ? W.dxa : dx;
     if ((rc = launch_ln_bwd(dy, x_last, Pf, W.statsf, eps, cur, W.lnpartf, D.M, d, L.DP, st))) return rc;
-    {
-        ProfScope prof(S_FINALIZE, st);
-        hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 31) / 32, 2, 1), dim3(1024), 0, st, W.lnpartf, D.G, L.DP, d, gPf, gPf + d,
-                           (size_t)0, (size_t)0);
-    }
-    LAUNCH_CHECK("ln_param_finalize_kernel");
+    // (the LayerNorm parameter gradients of the whole stack are reduced by the finalize launch at the end)
 
     WgradJobs J; memset(&J, 0, sizeof(J));
     J.MP = D.MP; J.M16 = D.M16; J.mchunk = D.mchunk;
@@ -621,16 +616,25 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
         S.dWqkv = W.sWqkv; S.dbqkv = W.sbqkv; S.dWo = W.sWo; S.dbo = W.sbo;
         S.dW1 = W.sW1; S.db1 = W.sb1; S.dW2 = W.sW2; S.db2 = W.sb2;
         S.ln1part = nullptr; S.ln2part = nullptr; S.nsplit = D.nsplit; S.G = D.G; S.slab_stride = W.slab_stride;
-        hipLaunchKernelGGL(encoder_finalize_kernel, dim3(grid_for(L.oln(0)), D.N), dim3(256), 0, st, S, L, dparams);
+        // LayerNorm jobs: the final norm (32-row partials of layernorm_bwd_kernel) and the 2N sublayer norms (row-tile partials of the
+        // LayerNorm-backward epilogues); outputs (a_2, b_2) are adjacent in the flat gradient
+        LnJobs LJ; memset(&LJ, 0, sizeof(LJ));
+        LJ.DP = L.DP; LJ.d = d; LJ.lnblocks = 2 * ((d + 31) / 32);
+        LJ.wblocks = (int)std::min<size_t>(64, (L.oln(0) + 4095) / 4096);
+        LJ.part[0] = W.lnpartf; LJ.out_a[0] = gPf; LJ.G[0] = D.G; LJ.n = 1;
+        for (int l = 0; l < D.N; ++l)
+            for (int k = 0; k < 2; ++k) {
+                LJ.part[LJ.n] = k == 0 ? W.lw[l].lnpart1 : W.lw[l].lnpart2;
+                LJ.out_a[LJ.n] = dparams + (size_t)l * L.stride() + L.oln(2 * k);
+                LJ.G[LJ.n] = D.GR; ++LJ.n;
+            }
+        hipLaunchKernelGGL(encoder_finalize_kernel, dim3(LJ.n * LJ.lnblocks + D.N * LJ.wblocks), dim3(1024), 0, st, S, L, dparams, LJ);
         LAUNCH_CHECK("encoder_finalize_kernel");
-        // the 2N sublayer LayerNorms: partials are contiguous [layer][norm][G][2][DP]; outputs (a_2, b_2) pairs are 2d apart
-        // inside a layer block, so launch per norm index with the layer stride
-        const size_t pstride = (size_t)2 * D.GR * 2 * L.DP;     // floats between layer l and l+1 for the same norm index
-        for (int k = 0; k < 2; ++k) {
-            float* oa = dparams + L.oln(2 * k);
-            hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 31) / 32, 2, D.N), dim3(1024), 0, st,
-                               k == 0 ? W.lw[0].lnpart1 : W.lw[0].lnpart2, D.GR, L.DP, d, oa, oa + d, pstride, L.stride());
-        }
+    }
+    else {      // no layers: only the final norm
+        ProfScope prof(S_FINALIZE, st);
+        hipLaunchKernelGGL(ln_param_finalize_kernel, dim3((d + 31) / 32, 2, 1), dim3(1024), 0, st, W.lnpartf, D.G, L.DP, d, gPf, gPf + d,
+                           (size_t)0, (size_t)0);
         LAUNCH_CHECK("ln_param_finalize_kernel");
     }
     return MMT_OK;

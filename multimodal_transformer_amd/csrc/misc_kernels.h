@@ -333,15 +333,42 @@ struct LayerSlabs {
     size_t slab_stride;                                                // floats between consecutive layers' slab sets
 };
 
-// grid = (blocks, n_layers): layer blockIdx.y's slabs -> its block of the flat gradient
-__global__ void encoder_finalize_kernel(LayerSlabs S0, LayerLayout L, float* __restrict__ grad0) {
+// ONE launch turns every partial result of the backward pass into the flat gradient (round 2 ran four: ~1.6 us of idle GPU between
+// any two kernels of a hipGraph plus a 6-9 us latency floor per tiny kernel).  1-D grid of 1024-thread workgroups:
+//   workgroups [0, nln * lnblocks): LayerNorm parameter gradients of job j = id / lnblocks: out_a[c] = sum_g part[g][1][c],
+//       out_b[c] = sum_g part[g][0][c] over the G row-tile partials, 32 columns x 32 row groups per workgroup, fixed order;
+//   the rest, wblocks per layer: the layer's weight / bias slabs summed over the window splits in a fixed order.
+#define MMT_MAX_LN_JOBS 40
+struct LnJobs { const float* part[MMT_MAX_LN_JOBS]; float* out_a[MMT_MAX_LN_JOBS]; int G[MMT_MAX_LN_JOBS]; int n, lnblocks, wblocks, DP, d; };
+
+__global__ __launch_bounds__(1024) void encoder_finalize_kernel(LayerSlabs S0, LayerLayout L, float* __restrict__ grad0, LnJobs J) {
+    __shared__ float red[32][33];
+    if ((int)blockIdx.x < J.n * J.lnblocks) {
+        const int job = blockIdx.x / J.lnblocks, r = blockIdx.x - job * J.lnblocks, which = r & 1, cb = r >> 1;
+        const float* part = J.part[job];
+        const int G = J.G[job];
+        const int cx = threadIdx.x & 31, rg = threadIdx.x >> 5, c = cb * 32 + cx;
+        float s = 0.f;
+        if (c < J.DP)
+            for (int g = rg; g < G; g += 32) s += part[(size_t)g * 2 * J.DP + (size_t)which * J.DP + c];
+        red[rg][cx] = s;
+        __syncthreads();
+        if (rg == 0 && c < J.d) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) t += red[i][cx];
+            (J.out_a[job] + (which ? 0 : J.d))[c] = t;          // (a_2, b_2) are adjacent in the parameter order
+        }
+        return;
+    }
+    const int wid = blockIdx.x - J.n * J.lnblocks, layer = wid / J.wblocks, wb = wid - layer * J.wblocks;
     LayerSlabs S = S0;
-    const size_t so = (size_t)blockIdx.y * S0.slab_stride;
+    const size_t so = (size_t)layer * S0.slab_stride;
     S.dWqkv += so; S.dbqkv += so; S.dWo += so; S.dbo += so; S.dW1 += so; S.db1 += so; S.dW2 += so; S.db2 += so;
-    float* grad = grad0 + (size_t)blockIdx.y * L.stride();
+    float* grad = grad0 + (size_t)layer * L.stride();
     const int d = L.d, f = L.f;
     const size_t n_w = L.oln(0);                   // weights and biases of the layer
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_w; idx += (size_t)gridDim.x * blockDim.x) {
+    for (size_t idx = (size_t)wb * blockDim.x + threadIdx.x; idx < n_w; idx += (size_t)J.wblocks * blockDim.x) {
         const float* src; size_t off, sstride;
         if (idx < L.oW1()) {                        // the four attention linears
             const int wi = (int)(idx / ((size_t)d * d + d));
