@@ -297,7 +297,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     from multimodal_transformer_amd import _lib
-    from multimodal_transformer_amd.functional import mse_sum_loss
+    from multimodal_transformer_amd.functional import mse_sum_loss, mse_sum_loss_backward
     cfg = dict(WORKLOADS[args.workload])
     if args.batch > 0:
         cfg["B"] = args.batch
@@ -318,8 +318,7 @@ def main():
         for p in params:
             p.grad = None
         x.grad = None
-        loss = mse_sum_loss(enc(x, mask), tgt, nvalid)
-        loss.backward()
+        mse_sum_loss_backward(enc(x, mask), tgt, nvalid)
 
     run = Runner(fwd_bwd, params, world, not args.no_graph, args.warmup)
     elapsed = run.timed(args.steps, dist, dev)
@@ -383,8 +382,7 @@ def main():
         def model_step():
             for p in mparams:
                 p.grad = None
-            loss = mse_sum_loss(model(xin, mask, lengths), tgt1, B * T)
-            loss.backward()
+            mse_sum_loss_backward(model(xin, mask, lengths), tgt1, B * T)
 
         mrun = Runner(model_step, mparams, 1, not args.no_graph, 3)
         el = mrun.timed(max(5, args.steps // 2))
@@ -418,8 +416,7 @@ def main():
         def pipe_step():
             for p in pparams:
                 p.grad = None
-            loss = mse_sum_loss(pmodel(praw, [T] * B, mask), ptgt, B * T)
-            loss.backward()
+            mse_sum_loss_backward(pmodel(praw, [T] * B, mask), ptgt, B * T)
 
         prun = Runner(pipe_step, pparams, 1, not args.no_graph, 3)
         pn = max(5, args.steps // 3)
@@ -463,8 +460,7 @@ def main():
         def mft_step():
             for p in mparams2:
                 p.grad = None
-            loss = mse_sum_loss(mmodel(xin2, mask2, [Tm] * Bm), tgt2, Bm * Tm)
-            loss.backward()
+            mse_sum_loss_backward(mmodel(xin2, mask2, [Tm] * Bm), tgt2, Bm * Tm)
 
         nst2 = max(5, args.steps // 2)
         mrun2 = Runner(mft_step, mparams2, 1, not args.no_graph, 3)
@@ -492,7 +488,7 @@ def main():
             for p in params:
                 p.grad = None
             xf.grad = None
-            mse_sum_loss(enc(xf, maskf), tgtf, Bf * T).backward()
+            mse_sum_loss_backward(enc(xf, maskf), tgtf, Bf * T)
 
         frun = Runner(full_step, params, 1, not args.no_graph, 2)
         nf = max(5, args.steps // 2)
@@ -522,7 +518,7 @@ def main():
         def mft4_step():
             for p in p4:
                 p.grad = None
-            mse_sum_loss(m4(x4, mask4, [T4] * B4), tgt4, B4 * T4).backward()
+            mse_sum_loss_backward(m4(x4, mask4, [T4] * B4), tgt4, B4 * T4)
 
         n4 = 5
         r4 = Runner(mft4_step, p4, 1, not args.no_graph, 2)

@@ -73,8 +73,11 @@ class _EncoderStackParamsFn(torch.autograd.Function):
     buffer in place with one collective and no staging copies (``parallel.allreduce_gradients``)."""
 
     @staticmethod
-    def forward(ctx, x, mask, h, d_ff, n_layers, eps, dropout_p, seed, *params):
-        flat = torch.cat([q.detach().reshape(-1) for q in params]).float()
+    def forward(ctx, x, mask, h, d_ff, n_layers, eps, dropout_p, seed, flat, *params):
+        # `flat`: the parameters' own storage when they are views of one buffer (multiTransformer.Encoder keeps them that way), else
+        # None and the buffer is assembled here (one concatenation kernel per step)
+        if flat is None:
+            flat = torch.cat([q.detach().reshape(-1) for q in params]).float()
         ctx.shapes = [tuple(q.shape) for q in params]
         ctx.inner = _Ctx()
         y = _EncoderStackFn.forward(ctx.inner, x, mask, flat, h, d_ff, n_layers, eps, dropout_p, seed, _needs=any(ctx.needs_input_grad))
@@ -90,7 +93,7 @@ class _EncoderStackParamsFn(torch.autograd.Function):
                 n *= v
             grads.append(dflat[off:off + n].view(shp))
             off += n
-        return (dx, None, None, None, None, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None, None, None, None, None) + tuple(grads)
 
 
 class _Ctx:
@@ -101,8 +104,8 @@ class _Ctx:
         self.saved_tensors = t
 
 
-def encoder_stack_params(x, mask, params, h, d_ff, n_layers, eps=1e-6, dropout_p=0.0, seed=0):
-    return _EncoderStackParamsFn.apply(x, mask, int(h), int(d_ff), int(n_layers), float(eps), float(dropout_p), int(seed), *params)
+def encoder_stack_params(x, mask, params, h, d_ff, n_layers, eps=1e-6, dropout_p=0.0, seed=0, flat=None):
+    return _EncoderStackParamsFn.apply(x, mask, int(h), int(d_ff), int(n_layers), float(eps), float(dropout_p), int(seed), flat, *params)
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -442,6 +445,25 @@ class _MseSumLossFn(torch.autograd.Function):
 def mse_sum_loss(pred, target, denom):
     """sum((pred - target)^2) / denom with the gradient produced in the same pass (train-step semantics of the reference)."""
     return _MseSumLossFn.apply(pred, target, float(denom))
+
+
+def mse_sum_loss_backward(pred, target, denom):
+    """``loss = mse_sum_loss(pred, target, denom); loss.backward()`` (transformer/SFT/train.py:133-139) without the two kernels autograd
+    spends on the seed gradient (a fill with 1.0 and a multiplication by it): the loss kernel's gradient 2 (pred - target) / denom is
+    handed straight to ``pred.backward``.  Returns the detached loss."""
+    lib = _lib.load()
+    _lib.require_hip(pred, target)
+    p_, t_ = _f32c(pred), _f32c(target)
+    if p_.shape != t_.shape:
+        raise ValueError("mse_sum_loss: pred %s and target %s differ in shape" % (tuple(pred.shape), tuple(target.shape)))
+    n = p_.numel()
+    loss = torch.empty((), dtype=torch.float32, device=p_.device)
+    dpred = torch.empty_like(p_)
+    scratch = torch.empty(lib.mmt_mse_sum_scratch_doubles(n), dtype=torch.float64, device=p_.device)
+    _lib.check(lib.mmt_mse_sum_forward(_lib.ptr(p_), _lib.ptr(t_), 1.0 / float(denom), _lib.ptr(loss), _lib.ptr(dpred), _lib.ptr(scratch),
+                                       n, _lib.stream_ptr()))
+    pred.backward(dpred.view(pred.shape))
+    return loss
 
 
 def check_device_errors():

@@ -156,6 +156,32 @@ class Encoder(nn.Module):
         super().__init__()
         self.layers = clones(layer, N)
         self.norm = LayerNorm(layer.size)
+        self._flat = None        # one buffer holding every parameter of the stack in the library's order; the Parameters are views of it
+
+    def _apply(self, fn, *args, **kwargs):        # .to() / .cuda() / .float() replace the parameters' storage
+        self._flat = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def _flat_storage(self, ps):
+        """The fused stack reads its 16 N + 2 parameter tensors as ONE flat fp32 buffer.  Concatenating them costs a kernel per step, so the
+        Parameters are re-seated once as views of such a buffer (like ``nn.LSTM.flatten_parameters``): optimizers and ``load_state_dict``
+        update them in place and the buffer follows.  Anything that replaces a parameter's storage is detected by the pointer check."""
+        flat = self._flat
+        if flat is not None and ps[0].data_ptr() == flat.data_ptr() and ps[-1].data_ptr() == flat.data_ptr() + 4 * (flat.numel() - ps[-1].numel()):
+            return flat
+        dev = ps[0].device
+        if torch.cuda.is_current_stream_capturing() or any(q.device != dev or q.dtype != torch.float32 or not q.is_contiguous() for q in ps):
+            return None
+        flat = torch.empty(sum(q.numel() for q in ps), dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for q in ps:
+                view = flat[off:off + q.numel()].view(q.shape)
+                view.copy_(q.data)
+                q.data = view
+                off += q.numel()
+        self._flat = flat
+        return flat
 
     def _fusable(self):
         if len(self.layers) == 0:
@@ -187,8 +213,10 @@ class Encoder(nn.Module):
         l0 = self.layers[0]
         p = l0.sublayer[0].dropout.p if self.training else 0.0
         seed = _lib.next_dropout_seed(x.device, 1) if p > 0.0 else 0
-        return F_hip.encoder_stack_params(x, mask, self.flat_parameters(), l0.self_attn.h, l0.feed_forward.w_1.weight.shape[0],
-                                          len(self.layers), eps=self.norm.eps, dropout_p=p, seed=seed)
+        ps = self.flat_parameters()
+        return F_hip.encoder_stack_params(x, mask, ps, l0.self_attn.h, l0.feed_forward.w_1.weight.shape[0],
+                                          len(self.layers), eps=self.norm.eps, dropout_p=p, seed=seed,
+                                          flat=self._flat_storage(ps) if x.is_cuda else None)
 
 
 def _encoder(embed_dim, h, d_ff, dropout, N):

@@ -223,6 +223,48 @@ def test_mse_sum_loss_and_gradient(dev):
         F.mse_sum_loss(torch.zeros(2, 3, device=dev), torch.zeros(3, 2, device=dev), 1.0)
 
 
+def test_loss_backward_helper_and_flat_parameter_storage(dev):
+    """mse_sum_loss_backward == mse_sum_loss(...).backward() bit for bit; the Encoder re-seats its parameters as views of ONE buffer
+    (no concatenation per step): optimiser updates and load_state_dict reach the kernels, .to() / .float() re-flatten"""
+    from multimodal_transformer_amd import functional as F, multiTransformer as MT
+    enc = MT.Encoder(MT.EncoderLayer(64, MT.MultiHeadedAttention(4, 64), MT.PositionwiseFeedForward(64, 96, 0.1), 0.1), 2)
+    assert enc._fusable()
+    p32 = R.gen_params(R.shapes_of(enc.state_dict()), 31)
+    enc.load_state_dict(p32)
+    enc = enc.to(dev).eval()
+    x = R.gen_normal("flat:x", (3, 20, 64), 31).to(dev).requires_grad_(True)
+    mask = R.prefix_mask([20, 11, 5], 20).to(dev)
+    tgt = R.gen_uniform("flat:t", (3, 20, 64), 31).to(dev)
+    F.mse_sum_loss(enc(x, mask), tgt, 36.0).backward()
+    g1 = [q.grad.clone() for q in enc.parameters()] + [x.grad.clone()]
+    ps = enc.flat_parameters()
+    base = enc._flat.data_ptr()
+    off = 0
+    for q in ps:                                        # every parameter is a view into the flat buffer, in the library's order
+        assert q.data_ptr() == base + 4 * off
+        off += q.numel()
+    for q in list(enc.parameters()) + [x]:
+        q.grad = None
+    loss = F.mse_sum_loss_backward(enc(x, mask), tgt, 36.0)
+    for a, b in zip(g1, [q.grad for q in enc.parameters()] + [x.grad]):
+        assert torch.equal(a, b)
+    ref = oracle.encoder_stack({k: v.double() for k, v in p32.items()}, "", x.detach().cpu().double(), mask.cpu().double(), 4)
+    assert abs(loss.item() - float(((ref - tgt.cpu().double()) ** 2).sum() / 36.0)) < 2e-2 * abs(loss.item())
+    # an in-place update (what optimisers and load_state_dict do) is seen by the next forward
+    y0 = enc(x, mask).detach().clone()
+    with torch.no_grad():
+        enc.norm.b_2.add_(0.5)
+    assert torch.allclose(enc(x, mask).detach(), y0 + 0.5, atol=1e-6)
+    sd = {k: v.clone() for k, v in enc.state_dict().items()}
+    enc.load_state_dict({k: v.cpu() for k, v in p32.items()})
+    assert torch.allclose(enc(x, mask).detach(), y0, atol=1e-6)
+    enc.load_state_dict(sd)
+    # .double().float() replaces every parameter's storage: the stack re-flattens by itself
+    enc = enc.double().float()
+    assert enc._flat is None
+    assert torch.allclose(enc(x, mask).detach(), y0 + 0.5, atol=1e-6) and enc._flat is not None
+
+
 def test_batched_ccc_on_device(dev):
     """device-side per-sequence CCC (mmt_ccc_forward) vs the values the reference's eval_ccc gave for the same rows
     (fixture `batching`, generated from transformer/SFT/train.py:42-50) and vs the numpy restatement at a large size"""
