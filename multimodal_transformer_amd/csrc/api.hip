@@ -280,12 +280,18 @@ static DropCfg no_drop() { return make_drop(0.f, 0, 0); }
 
 // Attention-probability dropout of `nlayers` layers: ONE launch draws every decision (stream 4l+0 of layer l) into the lane-mask
 // arrays mq / mk (layer l at + l * attn_mask_layer_words).  attn_mask.h.
-static int launch_mask_gen(uint16_t* mq, uint16_t* mk, const EncDims& D, int nlayers, float p, uint64_t seed, hipStream_t st) {
+static int fill_mask_gen(MaskGenParams& P, uint16_t* mq, uint16_t* mk, const EncDims& D, int nlayers, float p, uint64_t seed) {
     if (nlayers > 16) return fail(MMT_EUNSUPPORTED, "mask generator: %d layers > 16", nlayers);
-    MaskGenParams P; memset(&P, 0, sizeof(P));
+    memset(&P, 0, sizeof(P));
     P.lq = mq; P.lk = mk; P.nbh = D.B * D.h; P.nt = D.nt; P.nlayers = nlayers;
     P.layer_words = attn_mask_layer_words(P.nbh, P.nt);
     for (int l = 0; l < nlayers; ++l) { const DropCfg c = make_drop(p, seed, 4 * l + 0); P.thr16 = c.thr16; P.s0[l] = c.s0; P.s1[l] = c.s1; }
+    return MMT_OK;
+}
+static int launch_mask_gen(uint16_t* mq, uint16_t* mk, const EncDims& D, int nlayers, float p, uint64_t seed, hipStream_t st) {
+    MaskGenParams P;
+    int rc;
+    if ((rc = fill_mask_gen(P, mq, mk, D, nlayers, p, seed))) return rc;
     const size_t blocks = (size_t)P.nbh * P.nt * P.nt;
     ProfScope prof(S_MASK_GEN, st);
     hipLaunchKernelGGL(attn_mask_gen_kernel, dim3((unsigned)((blocks + 255) / 256), nlayers), dim3(256), 0, st, P);
@@ -416,14 +422,21 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
     hipStream_t st = static_cast<hipStream_t>(stream);
     const LayerLayout& L = D.L;
 
-    if (D.N > 0) {
+    if (D.N > 0 && dropout_p > 0.f) {
+        // weight preparation + every attention-dropout decision of this forward pass (and of its backward), all layers: one launch
+        MaskGenParams P;
+        if ((rc = fill_mask_gen(P, W.lw[0].maskQ, W.lw[0].maskK, D, D.N, dropout_p, seed))) return rc;
+        const size_t blocks = (size_t)P.nbh * P.nt * P.nt;
+        const int gen_blocks = (int)((blocks + 255) / 256), prep_blocks = std::min(grid_for(L.pstride() + L.qstride()), 64);
+        ProfScope prof(S_MASK_GEN, st);
+        hipLaunchKernelGGL(encoder_prep_maskgen_kernel, dim3((unsigned)(gen_blocks + prep_blocks), D.N), dim3(256), 0, st,
+                           params, W.wprep, W.bprep, L, gen_blocks, P);
+        LAUNCH_CHECK("encoder_prep_maskgen_kernel");
+    } else if (D.N > 0) {
         ProfScope prof(S_PREP, st);
         hipLaunchKernelGGL(encoder_prep_kernel, dim3(grid_for(L.pstride() + L.qstride()), D.N), dim3(256), 0, st,
                            params, W.wprep, W.bprep, L);
         LAUNCH_CHECK("encoder_prep_kernel");
-    }
-    if (D.N > 0 && dropout_p > 0.f) {      // every attention-dropout decision of this forward pass (and of its backward), all layers
-        if ((rc = launch_mask_gen(W.lw[0].maskQ, W.lw[0].maskK, D, D.N, dropout_p, seed, st))) return rc;
     }
     const float* xin = x;
     static const bool fuse_next_qkv = getenv("MMT_NO_CHAIN4") == nullptr;

@@ -107,10 +107,10 @@ __device__ __forceinline__ void park_lane_block(uint16_t* row, const uint32_t (&
 // at configs[3]).  The wave parks its 64 blocks in LDS and writes them out with the lanes laid along memory (no change in the
 // kernel's own time — it is bound by integer issue — but whole lines reach the fabric): LQ blocks of a wave are contiguous (1 KB per store instruction), LK blocks are
 // written as whole 128-byte lines by 8 lanes each.
-__global__ __launch_bounds__(256, 4) void attn_mask_gen_kernel(const MaskGenParams P) {
+__device__ __forceinline__ void attn_mask_gen_block(const MaskGenParams& P, int layer, int bx) {
     __shared__ __attribute__((aligned(16))) uint16_t patch[4][64 * MMT_MASK_LDS_ROW];
-    const int layer = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t g0 = (size_t)blockIdx.x * 256 + wave * 64;                 // first block of the wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t g0 = (size_t)bx * 256 + wave * 64;                         // first block of the wave
     const size_t per_bh = (size_t)P.nt * P.nt, total = (size_t)P.nbh * per_bh;
     if (g0 >= total) return;                                                // whole wave (no workgroup barrier below)
     const size_t g = g0 + lane;
@@ -154,6 +154,8 @@ __global__ __launch_bounds__(256, 4) void attn_mask_gen_kernel(const MaskGenPara
         }
     }
 }
+
+__global__ __launch_bounds__(256, 4) void attn_mask_gen_kernel(const MaskGenParams P) { attn_mask_gen_block(P, blockIdx.y, blockIdx.x); }
 
 __host__ inline size_t attn_mask_layer_words(int nbh, int nt) { return (size_t)nbh * nt * nt * 64; }      // uint16 words per layer and orientation
 

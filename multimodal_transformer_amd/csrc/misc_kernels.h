@@ -54,16 +54,16 @@ __device__ __forceinline__ int unpad_head(int c, const LayerLayout& L) {
     return (e < L.dk) ? head * L.dk + e : -1;
 }
 
-// grid = (blocks, n_layers); every element of the prepared block is computed from its coordinates
-__global__ void encoder_prep_kernel(const float* __restrict__ params, bf16* __restrict__ wprep,
-                                    float* __restrict__ bprep, LayerLayout L) {
-    const float* P = params + (size_t)blockIdx.y * L.stride();
-    bf16* W = wprep + (size_t)blockIdx.y * L.pstride();
-    float* Bp = bprep + (size_t)blockIdx.y * L.qstride();
+// Prepared (bf16, padded, transposed) weights and padded biases of one layer: block bx of nbx; every element is computed from its coordinates
+__device__ __forceinline__ void encoder_prep_block(const float* __restrict__ params, bf16* __restrict__ wprep, float* __restrict__ bprep,
+                                                   const LayerLayout& L, int layer, int bx, int nbx) {
+    const float* P = params + (size_t)layer * L.stride();
+    bf16* W = wprep + (size_t)layer * L.pstride();
+    float* Bp = bprep + (size_t)layer * L.qstride();
     const size_t total = L.pstride();
     const int d = L.d, f = L.f;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total + L.qstride();
-         idx += (size_t)gridDim.x * blockDim.x) {
+    for (size_t idx = (size_t)bx * blockDim.x + threadIdx.x; idx < total + L.qstride();
+         idx += (size_t)nbx * blockDim.x) {
         if (idx >= total) {                 // padded fp32 biases
             const int i = (int)(idx - total);
             float v = 0.f;
@@ -111,6 +111,21 @@ __global__ void encoder_prep_kernel(const float* __restrict__ params, bf16* __re
         }
         W[idx] = (bf16)v;
     }
+}
+// grid = (blocks, n_layers)
+__global__ void encoder_prep_kernel(const float* __restrict__ params, bf16* __restrict__ wprep,
+                                    float* __restrict__ bprep, LayerLayout L) {
+    encoder_prep_block(params, wprep, bprep, L, blockIdx.y, blockIdx.x, gridDim.x);
+}
+// Train mode: weight preparation and the dropout-bit generator are independent, so they share ONE launch (grid.y = layer): the first
+// `gen_blocks` workgroups of a layer draw its attention-dropout decisions, the last `gridDim.x - gen_blocks` prepare its weights — they
+// are dispatched last and run in the slots the generator's incomplete last round leaves free.  (Placed first, 900 small preparation
+// workgroups per layer at the generator's occupancy — its registers and 36 KB of LDS — made the launch 8 us LONGER than the two apart.)
+__global__ __launch_bounds__(256, 4) void encoder_prep_maskgen_kernel(const float* __restrict__ params, bf16* __restrict__ wprep,
+                                                                      float* __restrict__ bprep, LayerLayout L, int gen_blocks,
+                                                                      const MaskGenParams P) {
+    if ((int)blockIdx.x >= gen_blocks) { encoder_prep_block(params, wprep, bprep, L, blockIdx.y, blockIdx.x - gen_blocks, gridDim.x - gen_blocks); return; }
+    attn_mask_gen_block(P, blockIdx.y, blockIdx.x);
 }
 
 // generic: fp32 [N][K] (ld = K) -> bf16 [NP][KP] zero padded, optionally transposed source
