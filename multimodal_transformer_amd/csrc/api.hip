@@ -493,6 +493,10 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
                 c4.d = qkv_params(l + 1, nullptr);                 // A operand: the x2 tile in LDS
                 if ((rc = launch_rowchain(encoder_post_attn_fwd4_kernel, c4, false, S_CHAIN4_FWD, "encoder_post_attn_fwd4_kernel", st))) return rc;
             } else {
+                if (l + 1 == D.N) {        // last layer: the stack's final LayerNorm runs on the output tile while it is in LDS
+                    const float* Pf = params + (size_t)D.N * L.stride();
+                    ch.ln.a = Pf; ch.ln.b = Pf + d; ch.ln.eps = eps; ch.ln.y = y; ch.ln.stats = W.statsf; ch.ln.d = d;
+                }
                 if ((rc = launch_rowchain(encoder_post_attn_fwd_kernel, ch, false, S_OUTPROJ, "encoder_post_attn_fwd_kernel", st))) return rc;
                 if (l + 1 < D.N) {
                     RowGemmParams p = qkv_params(l + 1, w.xout);
@@ -502,10 +506,12 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
         }
         xin = w.xout;
     }
-    const float* Pf = params + (size_t)D.N * L.stride();
-    ProfScope prof(S_LN_FWD, st);
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(D.G), dim3(MMT_THREADS), 0, st, xin, Pf, Pf + d, eps, y, W.statsf, D.M, d);
-    LAUNCH_CHECK("layernorm_fwd_kernel");
+    if (D.N == 0) {                    // no layers: the final LayerNorm alone (otherwise it is the tail of the last layer's chain)
+        const float* Pf = params;
+        ProfScope prof(S_LN_FWD, st);
+        hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(D.G), dim3(MMT_THREADS), 0, st, xin, Pf, Pf + d, eps, y, W.statsf, D.M, d);
+        LAUNCH_CHECK("layernorm_fwd_kernel");
+    }
     return MMT_OK;
 }
 

@@ -648,7 +648,9 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
 }
 
 // ---- chained stages ------------------------------------------------------------------------------
-struct RowChain3 { RowGemmParams a, b, c; int lda_max, ldf, ldx, lda2; };   // LDS geometry decided by the host
+// final LayerNorm of the stack applied to the last stage's output tile while it is still in LDS (y == nullptr: none)
+struct LnOut { const float* a; const float* b; float eps; float* y; float* stats; int d; };
+struct RowChain3 { RowGemmParams a, b, c; int lda_max, ldf, ldx, lda2; LnOut ln; };   // LDS geometry decided by the host
 struct RowChain4 { RowGemmParams a, b, c, d; int lda_max, ldf, ldx, lda2; };
 
 template <typename CH>
@@ -669,6 +671,38 @@ __device__ __forceinline__ RowSmem rowchain_carve(char* smem, const CH& ch, bool
     return sm;
 }
 
+// y = LayerNorm(tile rows) -> global, with the reference's variant (unbiased std, eps added to std) and the (mean, 1/(std+eps)) pairs
+// its backward needs; the tile is the fp32 output of the stage that just ended on a barrier.  MMT_RTPR threads per row.
+__device__ __forceinline__ void ln_tile_out(const float* Xs, int ldx, const LnOut& lo, int M) {
+    constexpr int TPR = MMT_RTPR;
+    const int row = threadIdx.x / TPR, j = threadIdx.x % TPR, m = blockIdx.x * MMT_ROWS + row, K = lo.d;
+    const float* xr = Xs + row * ldx;
+    float s = 0.f;
+    for (int c = j * 4; c < K; c += 4 * TPR) { f32x4 v = *reinterpret_cast<const f32x4*>(xr + c); s += (v[0] + v[1]) + (v[2] + v[3]); }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    if (TPR == 16) s += __shfl_xor(s, 8);
+    const float mean = s / (float)K;
+    float q = 0.f;
+    for (int c = j * 4; c < K; c += 4 * TPR) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float t = v[i] - mean; q += t * t; }
+    }
+    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);
+    if (TPR == 16) q += __shfl_xor(q, 8);
+    const float rstd = 1.0f / (sqrtf(q / (float)(K - 1)) + lo.eps);
+    if (m >= M) return;
+    if (j == 0 && lo.stats) { lo.stats[2 * (size_t)m] = mean; lo.stats[2 * (size_t)m + 1] = rstd; }
+    for (int c = j * 4; c < K; c += 4 * TPR) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        const f32x4 av = *reinterpret_cast<const f32x4*>(lo.a + c), bv = *reinterpret_cast<const f32x4*>(lo.b + c);
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = av[i] * ((v[i] - mean) * rstd) + bv[i];
+        *reinterpret_cast<f32x4*>(lo.y + (size_t)m * K + c) = o;
+    }
+}
+
 // Forward, after the attention core of a layer:   x1 = x + drop(ctx Wo^T + bo)        (out-proj + residual; x1 kept in LDS)
 //                                                 hid = drop(relu(LN2(x1) W1^T + b1))  (hid kept in LDS as the next A tile)
 //                                                 x2 = x1 + drop(hid W2^T + b2)        (residual read from LDS)
@@ -678,7 +712,8 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
     rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X>(ch.a, sm);
     rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2>(ch.b, sm);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X>(ch.c, sm);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X>(ch.c, sm);
+    if (ch.ln.y) ln_tile_out(sm.Xs, sm.ldx, ch.ln, ch.c.M);          // last layer: the stack's final LayerNorm, from the tile in LDS
 }
 
 // The same chain followed by the NEXT layer's LayerNorm-1 + Q/K/V projection (its input x2 is already in LDS): every
