@@ -242,8 +242,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
         }
         ATT_STAMP(1);                                   // rescale decision, exponentials, row sums
         if (DROP) {                                     // zero the dropped probabilities; 1/(1-p) is applied once, to the output row
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] = keep_and(s[i], tw, i);
+            static_for<0, 16>([&](auto ic) { constexpr int i = decltype(ic)::value; s[i] = keep_and<i>(s[i], tw); });
         }
         ATT_STAMP(2);                                   // mask wait + selects
 #pragma unroll
@@ -413,17 +412,16 @@ __global__ __launch_bounds__(MMT_THREADS, DKP == 16 ? 4 : 2) void attn_bwd_dkv_k
         if (DROP) {
             // dropped probabilities Pd = P*m/(1-p):  dV^T += dO^T Pd ;  dS = P * ((dO V^T)*m/(1-p) - delta); delta unchanged.
             // m = bit j of the lane's tile word (LK layout: the key on the lane, query acc32_row(j, hh) in register j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            static_for<0, 4>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + 8 * g + 4 * hh);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int j = 4 * g + i;
-                    const float ms = __builtin_bit_cast(float, scale_bits & keep_bits(tw, j));
+                static_for<0, 4>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, j = 4 * g + i;
+                    const float ms = __builtin_bit_cast(float, scale_bits & keep_bits<j>(tw));
                     dp[j] = s[j] * fmaf(dp[j], ms, d4[i]);
                     s[j] *= ms;
-                }
-            }
+                });
+            });
         } else {
 #pragma unroll
             for (int j = 0; j < 16; ++j) dp[j] *= s[j];
@@ -548,8 +546,10 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_bwd_dq_kernel(
         }
         if (DROP) {
             // dS = P * ((dO V^T) * m/(1-p) - delta)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) dp[j] = s[j] * fmaf(dp[j], __builtin_bit_cast(float, scale_bits & keep_bits(tw, j)), negD);
+            static_for<0, 16>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                dp[j] = s[j] * fmaf(dp[j], __builtin_bit_cast(float, scale_bits & keep_bits<j>(tw)), negD);
+            });
         } else {
 #pragma unroll
             for (int j = 0; j < 16; ++j) dp[j] *= s[j];

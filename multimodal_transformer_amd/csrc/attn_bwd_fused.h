@@ -221,17 +221,16 @@ __global__ __launch_bounds__(MMT_FUSED_THREADS) void attn_bwd_fused16_kernel(
                 for (int j = 0; j < 16; ++j) s[j] *= kmul;
             }
             if (DROP) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                static_for<0, 4>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
                     const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + 8 * g + 4 * hh);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int j = 4 * g + i;
-                        const float ms = __builtin_bit_cast(float, scale_bits & keep_bits(tw, j));     // 1/(1-p) where (query of register j, this lane's key) was kept
+                    static_for<0, 4>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value, j = 4 * g + i;
+                        const float ms = __builtin_bit_cast(float, scale_bits & keep_bits<j>(tw));     // 1/(1-p) where (query of register j, this lane's key) was kept
                         dp[j] = s[j] * fmaf(dp[j], ms, d4[i]);
                         s[j] *= ms;
-                    }
-                }
+                    });
+                });
             } else {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) dp[j] *= s[j];

@@ -160,10 +160,21 @@ __global__ __launch_bounds__(256, 4) void attn_mask_gen_kernel(const MaskGenPara
 __host__ inline size_t attn_mask_layer_words(int nbh, int nt) { return (size_t)nbh * nt * nt * 64; }      // uint16 words per layer and orientation
 
 // ---- consumer side -------------------------------------------------------------------------------------------------
-// all-ones where bit i of the lane's tile word is set (kept), zero where it is clear (dropped): v_bfe_i32
-__device__ __forceinline__ uint32_t keep_bits(uint32_t w, int i) { return (uint32_t)__builtin_amdgcn_sbfe((int)w, i, 1); }
-__device__ __forceinline__ float keep_and(float v, uint32_t w, int i) {
-    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & keep_bits(w, i));
+// all-ones where bit I of the lane's tile word is set (kept), zero where it is clear (dropped): ONE v_bfe_i32.  Written as asm with
+// the bit index as an immediate: from `(int)w << (31 - i) >> 31` or __builtin_amdgcn_sbfe hipcc 7.2 builds v_and (1 << i) + v_cmp_ne +
+// v_cndmask for the AND that follows — three instructions per score where two do (found in the ISA of both attention hot loops).
+// (Its source is a word loaded long before and its consumer an ordinary v_and: no MFMA / transcendental hazard is involved.)
+template <int I> struct IdxC { static constexpr int value = I; };
+template <int B, int E, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) { f(IdxC<B>{}); static_for<B + 1, E>(f); }
+}
+template <int I> __device__ __forceinline__ uint32_t keep_bits(uint32_t w) {
+    uint32_t m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(w), "n"(I));
+    return m;
+}
+template <int I> __device__ __forceinline__ float keep_and(float v, uint32_t w) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & keep_bits<I>(w));
 }
 
 // ---- test hook: expand the generator's decisions to one byte per (bh, query, key) ------------------------------------
