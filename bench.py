@@ -14,7 +14,7 @@ Primary workload (`value`): the encoder-stack hot path of the SFT configuration 
                  kernels run on): algorithmic FLOPs per launch / average duration vs the dense bf16 MFMA peak;
   cpu_baseline — the CPU oracle (a port of the reference path, fp32 torch CPU) timed on this box's host
                  cores on a bounded sample of the same workload;
-  with_adam    — the same step followed by the reference's optimiser (Adam, foreach) [+ the all-reduce];
+  with_adam    — the same step followed by the reference's optimiser (Adam; optim.FlatAdam, one launch) [+ the all-reduce];
   full_model   — (N=1) the whole SFT sequence model NLPTransformer(512 -> d): embed + encoder + LSTM
                  decoder + MLP + mask, same batch shape, for the end-to-end picture (SURVEY §8f);
   raw_pipeline — (N=1) raw windows -> valence: the 3-modality MultiCNNTransformer (CNN k=2 + max-pool + Highway
@@ -330,7 +330,8 @@ def main():
     #      reported beside the headline, never as it ("with and without Adam + all-reduce")
     adam = None
     if rank == 0 or world > 1:
-        opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-4, foreach=True)
+        from multimodal_transformer_amd.optim import FlatAdam
+        opt = FlatAdam(params, lr=1e-4, weight_decay=1e-4)       # torch.optim.Adam's update as one launch over the flat parameter buffer
         def step_adam():
             run.step()
             opt.step()
@@ -344,7 +345,8 @@ def main():
             step_adam()
         torch.cuda.synchronize()
         adam = {"ms_per_step": round(1e3 * (time.perf_counter() - t0) / args.steps, 4),
-                "what": "step + torch.optim.Adam(foreach) on the %d parameter tensors%s" % (len(params), " + gradient all-reduce" if world > 1 else "")}
+                "what": "step + Adam (optim.FlatAdam: torch.optim.Adam's update, one launch over the flat buffer of the %d parameter tensors)%s"
+                        % (len(params), " + gradient all-reduce" if world > 1 else "")}
 
     # ---- per-kernel timing (HIP events on the launch stream), eager, outside the timed region
     roofline, kernel_ms = None, {}

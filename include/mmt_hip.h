@@ -170,6 +170,15 @@ size_t mmt_mse_sum_scratch_doubles(size_t n);
 int mmt_mse_sum_forward(const float* pred, const float* target, float inv_denom, float* loss, float* dpred, double* scratch,
                         size_t n, mmt_stream_t stream);
 
+/* ---- Optimiser step.
+ * Replaces optimizer.step() of torch.optim.Adam(lr, weight_decay) (L2 form, not AdamW)   transformer/SFT/train.py:621, called at :141
+ * on `nchunks` contiguous fp32 ranges (parameter, gradient, first and second moment of chunk c: counts[c] elements each) in one
+ * launch per 48 chunks.  `step` = 1, 2, ... (bias corrections 1 - beta^step are taken on the host).  The pointer arrays are HOST arrays
+ * of device pointers. */
+int mmt_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                  const size_t* counts, int nchunks, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int step, mmt_stream_t stream);
+
 /* ---- Concordance correlation coefficient per sequence, on the device.
  * Replaces eval_ccc + the per-sequence host loop of evaluate()     transformer/SFT/train.py:42-50, :236-238
  * pred, target: (B, T) fp32 row-major (the (B,T,1) valence tensors); lengths: B int32 on the device; sequence b uses its first

@@ -48,6 +48,7 @@ SIGNATURES = {
     "mmt_convpool_backward": (_I, [_P] * 6 + [_SZ] + [_I] * 4 + [_P]),
     "mmt_mse_sum_scratch_doubles": (_SZ, [_SZ]),
     "mmt_mse_sum_forward": (_I, [_P, _P, _F, _P, _P, _P, _SZ, _P]),
+    "mmt_adam_step": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _F, _I, _P]),
     "mmt_ccc_forward": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "mmt_debug_dropout_mask": (_I, [_F, _U64, _c.c_uint32, _U64, _c.c_uint32, _P, _P, _P]),
     "mmt_debug_poison_lds": (_I, [_c.c_uint32, _P, _P]),

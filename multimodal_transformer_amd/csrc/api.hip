@@ -1214,6 +1214,30 @@ extern "C" int mmt_mse_sum_forward(const float* pred, const float* target, float
     return MMT_OK;
 }
 
+// ------------------------------------------------------------------------------------ optimiser
+extern "C" int mmt_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                             const size_t* counts, int nchunks, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             int step, mmt_stream_t stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !counts) return fail(MMT_EINVAL, "null pointer argument");
+    if (nchunks <= 0 || step <= 0) return fail(MMT_EINVAL, "adam: nchunks %d, step %d must be positive", nchunks, step);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    for (int c0 = 0; c0 < nchunks; c0 += MMT_ADAM_MAX_CHUNKS) {
+        AdamChunks C; memset(&C, 0, sizeof(C));
+        const int nc = std::min(MMT_ADAM_MAX_CHUNKS, nchunks - c0);
+        size_t nmax = 0;
+        for (int c = 0; c < nc; ++c) {
+            C.p[c] = params[c0 + c]; C.g[c] = grads[c0 + c]; C.m[c] = exp_avg[c0 + c]; C.v[c] = exp_avg_sq[c0 + c]; C.n[c] = counts[c0 + c];
+            if (!C.p[c] || !C.g[c] || !C.m[c] || !C.v[c]) return fail(MMT_EINVAL, "adam: null pointer in chunk %d", c0 + c);
+            nmax = std::max(nmax, counts[c0 + c]);
+        }
+        const int gx = (int)std::min<size_t>(512, (nmax + 1023) / 1024);
+        hipLaunchKernelGGL(adam_step_kernel, dim3(gx > 0 ? gx : 1, nc), dim3(256), 0, st, C, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+        LAUNCH_CHECK("adam_step_kernel");
+    }
+    return MMT_OK;
+}
+
 // ------------------------------------------------------------------------------------ metric
 extern "C" int mmt_ccc_forward(const float* pred, const float* target, const int32_t* lengths, double* ccc, int B, int T, mmt_stream_t stream) {
     if (!pred || !target || !lengths || !ccc) return fail(MMT_EINVAL, "null pointer argument");

@@ -509,3 +509,27 @@ __global__ __launch_bounds__(256) void mse_sum_final_kernel(const double* __rest
     }
     if (threadIdx.x == 0) loss[0] = (float)(red[0] * (double)inv_denom);
 }
+
+
+// Adam step of the reference's optimiser (torch.optim.Adam with L2 weight decay: transformer/SFT/train.py:621) on up to
+// MMT_ADAM_MAX_CHUNKS contiguous parameter ranges in ONE launch: the encoder's parameters, gradients and moments are flat buffers
+// (multiTransformer.Encoder._flat_storage, functional._EncoderStackParamsFn), so the whole stack is one chunk; torch's foreach
+// implementation runs ~10 multi-tensor kernels over the 98 tensors (90 us at configs[3]).  grid = (blocks, chunks).
+#define MMT_ADAM_MAX_CHUNKS 48
+struct AdamChunks { float* p[MMT_ADAM_MAX_CHUNKS]; const float* g[MMT_ADAM_MAX_CHUNKS]; float* m[MMT_ADAM_MAX_CHUNKS]; float* v[MMT_ADAM_MAX_CHUNKS];
+                    unsigned long long n[MMT_ADAM_MAX_CHUNKS]; };
+__global__ __launch_bounds__(256) void adam_step_kernel(const AdamChunks C, float lr, float beta1, float beta2, float eps, float wd,
+                                                        float bc1, float bc2_sqrt) {       // bc1 = 1 - beta1^t, bc2_sqrt = sqrt(1 - beta2^t)
+    const int c = blockIdx.y;
+    float* __restrict__ p = C.p[c]; const float* __restrict__ g = C.g[c]; float* __restrict__ m = C.m[c]; float* __restrict__ v = C.v[c];
+    const size_t n = C.n[c];
+    const float step = lr / bc1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float pi = p[i];
+        const float gi = g[i] + wd * pi;                          // grad = grad.add(param, alpha=weight_decay)
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;       // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        m[i] = mi; v[i] = vi;
+        p[i] = pi - step * (mi / (sqrtf(vi) / bc2_sqrt + eps));   // param.addcdiv_(exp_avg, exp_avg_sq.sqrt() / bias_correction2_sqrt + eps, value=-step_size)
+    }
+}

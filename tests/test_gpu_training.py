@@ -90,3 +90,33 @@ def test_loss_decreases_in_train_mode(dev):
         hist.append(loss.item())
     print("loss: first %.4f  last %.4f" % (hist[0], hist[-1]))
     assert np.isfinite(hist).all() and np.mean(hist[-5:]) < 0.6 * np.mean(hist[:5])
+
+
+def test_flat_adam_matches_torch_adam(dev):
+    """optim.FlatAdam == torch.optim.Adam (L2 weight decay, bias-corrected moments; transformer/SFT/train.py:621) on the same gradients:
+    the encoder's 34 tensors as ONE range (parameters and gradients are views of flat buffers), loose tensors as ranges of their own"""
+    import copy
+    from multimodal_transformer_amd import functional as F, multiTransformer as MT
+    from multimodal_transformer_amd.optim import FlatAdam
+    model = MT.NLPTransformer(512, embed_dim=64, h=4, N=2, device=dev)
+    model.load_state_dict(R.gen_params(R.shapes_of(model.state_dict()), 37))
+    model = model.to(dev).eval()
+    ref = copy.deepcopy(model)
+    lengths = [20, 13, 6]
+    mask = R.prefix_mask(lengths, 20).to(dev)
+    opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-2)
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-3, weight_decay=1e-2)
+    for i in range(4):
+        x = torch.tanh(R.gen_normal("fadam:x%d" % i, (3, 20, 512), 37)).to(dev)
+        tgt = (R.gen_uniform("fadam:t%d" % i, (3, 20, 1), 37) * R.prefix_mask(lengths, 20)).to(dev)
+        opt.zero_grad(set_to_none=True)
+        F.mse_sum_loss_backward(model(x, mask, lengths), tgt, sum(lengths))
+        for pm, pr in zip(model.parameters(), ref.parameters()):         # both optimisers see the SAME gradients
+            pr.grad = None if pm.grad is None else pm.grad.clone()
+        if i == 0:      # the whole encoder stack is one range; embed, decoder and read-out tensors are ranges of their own
+            live = [q for q in model.parameters() if q.grad is not None]
+            assert len(FlatAdam._ranges(live)) <= len(live) - 30
+        opt.step()
+        opt_ref.step()
+    for (k, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6, k
