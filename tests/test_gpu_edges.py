@@ -57,9 +57,11 @@ def test_all_sequences_empty(dev):
     _check_encoder(dev, 40, 4, 2, 2, 9, [0, 0], "edge:allempty")
 
 
-@pytest.mark.parametrize("B,T,d,h", [(1, 1, 128, 8), (1, 2, 40, 4), (5, 31, 256, 8), (2, 33, 128, 8), (1, 64, 128, 8), (1, 65, 40, 4)])
+@pytest.mark.parametrize("B,T,d,h", [(1, 1, 128, 8), (1, 2, 40, 4), (5, 31, 256, 8), (2, 33, 128, 8), (1, 64, 128, 8), (1, 65, 40, 4),
+                                     (2, 257, 64, 4), (1, 512, 32, 2), (2, 256, 64, 4), (1, 513, 32, 2)])
 def test_tile_boundaries(dev, B, T, d, h):
-    """T around the 32-window tile size, single sequences / single windows"""
+    """T around the 32-window tile size, single sequences / single windows; T = 257 and 512 are the ends of the one-kernel attention
+    backward's range (9 and 16 key tiles at d_k = 16), 256 and 513 the neighbours that take the two-kernel path"""
     lengths = [max(1, T - 3 * i) for i in range(B)]
     _check_encoder(dev, d, h, 2, B, T, lengths, "edge:%dx%dx%d" % (B, T, d))
 
