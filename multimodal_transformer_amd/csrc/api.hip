@@ -36,7 +36,7 @@ static int fail(int code, const char* fmt, ...) {
 // dominant kernel's average duration on the stream the kernels really run on.
 enum Site { S_PREP = 0, S_LN1_QKV, S_ATTN_FWD, S_OUTPROJ, S_LN2_FFN1, S_FFN2, S_LN_FWD, S_LN_BWD, S_BWD_FFN2, S_BWD_FFN1_LN2,
             S_BWD_OUTPROJ, S_ATTN_BWD, S_ATTN_BWD_DQ, S_BWD_QKV_LN1, S_WGRAD, S_FINALIZE, S_OTHER,
-            S_LINEAR_FWD, S_LINEAR_BWD_DX, S_LINEAR_WGRAD, S_LSTM_FWD, S_LSTM_BWD, S_MEM_FWD, S_MEM_BWD, S_CONV_FWD, S_CONV_BWD, S_CHAIN4_FWD, S_ATTN_BWD_FUSED, S_MASK_GEN, S_COUNT };
+            S_LINEAR_FWD, S_LINEAR_BWD_DX, S_LINEAR_WGRAD, S_LSTM_FWD, S_LSTM_BWD, S_MEM_FWD, S_MEM_BWD, S_CONV_FWD, S_CONV_BWD, S_CHAIN4_FWD, S_ATTN_BWD_FUSED, S_MASK_GEN, S_BWD_BOUNDARY, S_COUNT };
 static const char* const g_site_names[S_COUNT] = {
     "encoder_prep_kernel", "rowgemm<FRAG,LN>:ln1+qkv", "attn_fwd_kernel", "chain:outproj+res>ln2+ffn1>ffn2+res",
     "rowgemm<PLAIN,LN>:ln2+ffn1+relu", "rowgemm<PLAIN>:ffn2+res", "layernorm_fwd_kernel", "layernorm_bwd_kernel",
@@ -44,7 +44,8 @@ static const char* const g_site_names[S_COUNT] = {
     "attn_bwd_dq_kernel", "rowgemm<LNBWD>:bwd_qkv+ln1", "wgrad_kernel", "finalize_kernels", "other",
     "rowgemm<PLAIN>:linear_fwd", "rowgemm<PLAIN>:linear_bwd_dx", "wgrad_kernel:linear", "lstm_scan_fwd_kernel", "lstm_scan_bwd_kernel",
     "mfn_mem_scan_fwd_kernel", "mfn_mem_scan_bwd_kernel", "convpool_fwd_kernel", "convpool_bwd_kernel",
-    "chain:outproj+res>ln2+ffn1>ffn2+res>ln1+qkv(next)", "attn_bwd_fused16_kernel", "attn_mask_gen_kernel"};
+    "chain:outproj+res>ln2+ffn1>ffn2+res>ln1+qkv(next)", "attn_bwd_fused16_kernel", "attn_mask_gen_kernel",
+    "chain:bwd_qkv+ln1>bwd_ffn2(below)>bwd_ffn1+ln2>bwd_outproj->dO"};
 struct ProfRec { int site; hipEvent_t a, b; };
 static bool g_prof = false;
 static ProfRec* g_recs = nullptr;
@@ -247,14 +248,16 @@ static int chain_extra_kp(const RowChain3&) { return 0; }
 static int chain_extra_kp(const RowChain4& ch) { return ch.d.KP; }
 
 template <typename K, typename CH>
-static int launch_rowchain(K kernel, CH& ch, bool lnbwd, int site, const char* name, hipStream_t st) {   // lnbwd: stage b is a LayerNorm backward
+static int launch_rowchain(K kernel, CH& ch, bool lnbwd, int site, const char* name, hipStream_t st, int lnb_np = 0) {
+    // lnbwd: the chain holds LayerNorm-backward stages of output width lnb_np (default: stage b's)
     // LDS geometry shared by the stages
     int kmax = ch.a.KP > ch.b.KP ? ch.a.KP : ch.b.KP;             // stages reading sm.As: a (global) and whichever of b/c stages via Xs
     if (ch.c.KP > kmax) kmax = ch.c.KP;
     if (chain_extra_kp(ch) > kmax) kmax = chain_extra_kp(ch);
     ch.lda_max = kmax + 8;
     int fw = 128;
-    if (lnbwd && ch.b.NP > fw) fw = ch.b.NP;                   // LayerNorm-backward epilogue needs the full row
+    if (lnb_np == 0) lnb_np = ch.b.NP;
+    if (lnbwd && lnb_np > fw) fw = lnb_np;                     // LayerNorm-backward epilogue needs the full row
     ch.ldf = fw + 4;
     const bool with_g = lnbwd && !ch.b.no_gs;                  // ... and a second fp32 tile unless the column sums recompute x-hat
     const size_t lds = rowchain_lds_bytes(ch, with_g);
@@ -565,37 +568,60 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
     };
 
     float* other = W.dxb;
-    for (int l = D.N - 1; l >= 0; --l) {
+    // dx2 -> dh -> dx1 -> dO fragments of layer l (reads `cur` = dx2, writes `other` = dx1); dh and drop'(dx1) stay in LDS
+    auto build_chain = [&](int l, RowChain3& ch) {
         const LayerWs& w = W.lw[l];
         const float* P = params + (size_t)l * L.stride();
         const bf16* wp = W.wprep + (size_t)l * L.pstride();
-        const float* xin = (l > 0) ? W.lw[l - 1].xout : x;
-        {   // dx2 -> dh -> dx1 -> dO fragments, one kernel; dh and dx1 stay in LDS
-            RowChain3 ch; memset(&ch, 0, sizeof(ch));
-            {   RowGemmParams& p = ch.a; p = rg_zero();           // dh = (drop'(dx2) W2) * relu'(hid)   [emits dx2, dh as bf16 rows]
-                p.M = D.M; p.K = d; p.KP = L.DP; p.N = f; p.NP = L.FP;
-                p.A = cur; p.lda = d; p.A_out = w.dx2; p.lda_out = L.DP;
-                p.W = wp + L.pW2T();
-                p.relu_mask = w.hid; p.ldm = L.FP;          // hid > 0  <=>  ReLU passed AND the unit was kept
-                p.mask_scale = make_drop(dropout_p, seed, 4 * l + 2).scale;
-                p.a_drop = make_drop(dropout_p, seed, 4 * l + 3);   // gradient of the dropped sublayer-1 output
-                p.out_bf16 = w.dh; p.ldo16 = L.FP; p.n_store16 = L.FP; }
-            {   RowGemmParams& p = ch.b; p = rg_zero();           // dx1 = dx2 + LN2bwd(dh W1)
-                p.M = D.M; p.K = L.FP; p.KP = L.FP; p.N = d; p.NP = L.DP;
-                p.W = wp + L.pW1T();
-                p.x = w.x1; p.ldx = d; p.st = w.stats2; p.ln_a = P + L.oln(2); p.eps = eps; p.d_real = d;
-                p.dres = cur; p.lddres = d; p.out_f32 = other; p.ldo = d; p.colpart = w.lnpart2;
-                p.no_gs = L.DP > 128;                               // d_model > 128: a second fp32 tile would leave one workgroup per CU
-                p.next_drop = make_drop(dropout_p, seed, 4 * l + 1);   // gradient of the dropped sublayer-0 output, applied to the next A tile
-                p.next_lda = L.DP + 8; }
-            {   RowGemmParams& p = ch.c; p = rg_zero();           // dO = drop'(dx1) Wo -> fragments + delta   [emits dx1 as bf16 rows]
-                p.M = D.M; p.K = d; p.KP = L.DP; p.N = L.HD; p.NP = L.HDP;
-                p.A_out = w.dx1; p.lda_out = L.DP;                 // (its A tile, drop'(dx1) in bf16, was left in LDS by the stage before)
-                p.W = wp + L.pWoT();
-                p.fragR[0] = W.dOR;
-                p.T = T; p.Tp = D.Tp; p.h = h; p.DKP = L.DKP; p.nwhich = 1;
-                p.ctx = w.ctx; p.ldctx = L.HDP; p.delta = W.delta; }
-            ch.ldx = 0; ch.lda2 = L.FP + 8;                        // no fp32 tile kept between the stages
+        memset(&ch, 0, sizeof(ch));
+        {   RowGemmParams& p = ch.a; p = rg_zero();           // dh = (drop'(dx2) W2) * relu'(hid)   [emits dx2, dh as bf16 rows]
+            p.M = D.M; p.K = d; p.KP = L.DP; p.N = f; p.NP = L.FP;
+            p.A = cur; p.lda = d; p.A_out = w.dx2; p.lda_out = L.DP;
+            p.W = wp + L.pW2T();
+            p.relu_mask = w.hid; p.ldm = L.FP;          // hid > 0  <=>  ReLU passed AND the unit was kept
+            p.mask_scale = make_drop(dropout_p, seed, 4 * l + 2).scale;
+            p.a_drop = make_drop(dropout_p, seed, 4 * l + 3);   // gradient of the dropped sublayer-1 output
+            p.out_bf16 = w.dh; p.ldo16 = L.FP; p.n_store16 = L.FP; }
+        {   RowGemmParams& p = ch.b; p = rg_zero();           // dx1 = dx2 + LN2bwd(dh W1)
+            p.M = D.M; p.K = L.FP; p.KP = L.FP; p.N = d; p.NP = L.DP;
+            p.W = wp + L.pW1T();
+            p.x = w.x1; p.ldx = d; p.st = w.stats2; p.ln_a = P + L.oln(2); p.eps = eps; p.d_real = d;
+            p.dres = cur; p.lddres = d; p.out_f32 = other; p.ldo = d; p.colpart = w.lnpart2;
+            p.no_gs = L.DP > 128;                               // d_model > 128: a second fp32 tile would leave one workgroup per CU
+            p.next_drop = make_drop(dropout_p, seed, 4 * l + 1);   // gradient of the dropped sublayer-0 output, applied to the next A tile
+            p.next_lda = L.DP + 8; }
+        {   RowGemmParams& p = ch.c; p = rg_zero();           // dO = drop'(dx1) Wo -> fragments + delta   [emits dx1 as bf16 rows]
+            p.M = D.M; p.K = d; p.KP = L.DP; p.N = L.HD; p.NP = L.HDP;
+            p.A_out = w.dx1; p.lda_out = L.DP;                 // (its A tile, drop'(dx1) in bf16, was left in LDS by the stage before)
+            p.W = wp + L.pWoT();
+            p.fragR[0] = W.dOR;
+            p.T = T; p.Tp = D.Tp; p.h = h; p.DKP = L.DKP; p.nwhich = 1;
+            p.ctx = w.ctx; p.ldctx = L.HDP; p.delta = W.delta; }
+        ch.ldx = 0; ch.lda2 = L.FP + 8;                        // no fp32 tile kept between the stages
+    };
+    // dx = dx1 + LN1bwd(dQKV Wqkv) of layer l (reads `other` = dx1, writes `out`)
+    auto build_qkv = [&](int l, float* out) {
+        const LayerWs& w = W.lw[l];
+        const float* P = params + (size_t)l * L.stride();
+        const bf16* wp = W.wprep + (size_t)l * L.pstride();
+        RowGemmParams p = rg_zero();
+        p.M = D.M; p.K = L.NQ; p.KP = L.NQ; p.N = d; p.NP = L.DP;
+        p.A = w.dqkv; p.a_bf16 = 1; p.lda = L.NQ;
+        p.W = wp + L.pWqkvT();
+        p.x = (l > 0) ? W.lw[l - 1].xout : x; p.ldx = d; p.st = w.stats1; p.ln_a = P + L.oln(0); p.eps = eps; p.d_real = d;
+        p.dres = other; p.lddres = d; p.out_f32 = out; p.ldo = d; p.colpart = w.lnpart1;
+        p.kchunk = (L.NQ > 512) ? 512 : 0;                     // d_model = 256: K = 768; half of the A tile in LDS at a time
+        p.no_gs = (L.DP > 128) || p.kchunk;                    // (both live in the WIDE instance of the kernel)
+        return p;
+    };
+    // Layers l >= 1 close (bwd_qkv + LayerNorm-1 backward) inside the kernel that opens layer l-1 (encoder_bwd_boundary_kernel) unless
+    // the model is wide (the WIDE stages do not fit two workgroups per CU together) or MMT_NO_BWD_BOUNDARY=1
+    static const bool fuse_boundary = getenv("MMT_NO_BWD_BOUNDARY") == nullptr;
+    const bool boundary = fuse_boundary && L.DP <= 128 && L.NQ <= 512;
+    for (int l = D.N - 1; l >= 0; --l) {
+        const LayerWs& w = W.lw[l];
+        if (l == D.N - 1 || !boundary) {
+            RowChain3 ch; build_chain(l, ch);
             if (ch.b.no_gs) rc = launch_rowchain(encoder_pre_attn_bwd_kernel<true>, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st);
             else rc = launch_rowchain(encoder_pre_attn_bwd_kernel<false>, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st);
             if (rc) return rc;
@@ -603,15 +629,15 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
         if ((rc = launch_attn_bwd(L.DKP, w.QR, w.KR, w.VR, W.dOR, w.lse, W.delta, mask,
                                   w.dqkv, D, st, make_drop(dropout_p, seed, 4 * l + 0), w.maskQ, w.maskK))) return rc;
         float* dxin = (l > 0) ? cur : dx;
-        {   // dx = dx1 + LN1bwd(dQKV Wqkv)
-            RowGemmParams p = rg_zero();
-            p.M = D.M; p.K = L.NQ; p.KP = L.NQ; p.N = d; p.NP = L.DP;
-            p.A = w.dqkv; p.a_bf16 = 1; p.lda = L.NQ;
-            p.W = wp + L.pWqkvT();
-            p.x = xin; p.ldx = d; p.st = w.stats1; p.ln_a = P + L.oln(0); p.eps = eps; p.d_real = d;
-            p.dres = other; p.lddres = d; p.out_f32 = dxin; p.ldo = d; p.colpart = w.lnpart1;
-            p.kchunk = (L.NQ > 512) ? 512 : 0;                     // d_model = 256: K = 768; half of the A tile in LDS at a time
-            p.no_gs = (L.DP > 128) || p.kchunk;                    // (both live in the WIDE instance of the kernel)
+        if (l > 0 && boundary) {
+            RowChain3 below; build_chain(l - 1, below);        // (its stages read `cur` = the dx this kernel's first stage writes)
+            RowChain4 c4; memset(&c4, 0, sizeof(c4));
+            c4.a = build_qkv(l, dxin);
+            c4.a.next_drop = below.a.a_drop; c4.a.next_lda = below.a.KP + 8;      // next A tile = bf16(drop'(dx)), left in LDS
+            c4.b = below.a; c4.c = below.b; c4.d = below.c; c4.ldx = 0; c4.lda2 = below.lda2;
+            if ((rc = launch_rowchain(encoder_bwd_boundary_kernel, c4, true, S_BWD_BOUNDARY, "encoder_bwd_boundary_kernel", st, L.DP))) return rc;
+        } else {
+            RowGemmParams p = build_qkv(l, dxin);
             if ((rc = launch_rowgemm<EPI_LNBWD, false>(p, st, S_BWD_QKV_LN1))) return rc;
         }
         // weight-gradient jobs of this layer (run later, all layers in one launch)
