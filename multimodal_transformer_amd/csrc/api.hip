@@ -126,7 +126,9 @@ static int make_dims(EncDims& D, int B, int T, int d, int h, int f, int N) {
         const size_t bwd_chain = (size_t)MMT_ROWS * ((kmax + 8) * 2 + (fw + 4) * 4 * (no_gs ? 1 : 2) + (L.FP + 8) * 2);
         const size_t fwd_chain = (size_t)MMT_ROWS * ((kmax + 8) * 2 + (128 + 4) * 4 + (L.DP + 4) * 4 + (L.FP + 8) * 2);
         const size_t bwd_qkv = rowgemm_lds_bytes(EPI_LNBWD, false, L.NQ, L.DP, L.NQ > 512 ? 512 : 0, no_gs || L.NQ > 512);
-        const size_t worst = std::max(std::max(bwd_chain, fwd_chain), bwd_qkv);
+        const int bk = std::max(std::max(L.NQ > 512 ? 512 : L.NQ, L.DP), L.FP);
+        const size_t boundary = (size_t)MMT_ROWS * ((bk + 8) * 2 + (fw + 4) * 4 * ((no_gs || L.NQ > 512) ? 1 : 2) + (L.FP + 8) * 2);
+        const size_t worst = std::max(std::max(std::max(bwd_chain, fwd_chain), bwd_qkv), boundary);
         if (worst > 160 * 1024)
             return fail(MMT_EUNSUPPORTED, "d_model %d / d_ff %d: a %d-window tile of the row kernels needs %zu B of LDS (160 KB per CU)",
                         d, f, MMT_ROWS, worst);
@@ -251,7 +253,8 @@ template <typename K, typename CH>
 static int launch_rowchain(K kernel, CH& ch, bool lnbwd, int site, const char* name, hipStream_t st, int lnb_np = 0) {
     // lnbwd: the chain holds LayerNorm-backward stages of output width lnb_np (default: stage b's)
     // LDS geometry shared by the stages
-    int kmax = ch.a.KP > ch.b.KP ? ch.a.KP : ch.b.KP;             // stages reading sm.As: a (global) and whichever of b/c stages via Xs
+    const int akp = (ch.a.kchunk > 0 && ch.a.kchunk < ch.a.KP) ? ch.a.kchunk : ch.a.KP;     // K-chunked first stage: one chunk in LDS
+    int kmax = akp > ch.b.KP ? akp : ch.b.KP;                     // stages reading sm.As: a (global) and whichever of b/c stages via Xs
     if (ch.c.KP > kmax) kmax = ch.c.KP;
     if (chain_extra_kp(ch) > kmax) kmax = chain_extra_kp(ch);
     ch.lda_max = kmax + 8;
@@ -259,7 +262,7 @@ static int launch_rowchain(K kernel, CH& ch, bool lnbwd, int site, const char* n
     if (lnb_np == 0) lnb_np = ch.b.NP;
     if (lnbwd && lnb_np > fw) fw = lnb_np;                     // LayerNorm-backward epilogue needs the full row
     ch.ldf = fw + 4;
-    const bool with_g = lnbwd && !ch.b.no_gs;                  // ... and a second fp32 tile unless the column sums recompute x-hat
+    const bool with_g = lnbwd && !(ch.a.no_gs || ch.b.no_gs || ch.c.no_gs);      // ... and a second fp32 tile unless the column sums recompute x-hat
     const size_t lds = rowchain_lds_bytes(ch, with_g);
     if (lds > 160 * 1024) return fail(MMT_EUNSUPPORTED, "fused row chain needs %zu B of LDS", lds);
     static const void* configured[4] = {nullptr, nullptr, nullptr, nullptr};     // both chain kernels share this instantiation
@@ -615,9 +618,9 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
         return p;
     };
     // Layers l >= 1 close (bwd_qkv + LayerNorm-1 backward) inside the kernel that opens layer l-1 (encoder_bwd_boundary_kernel) unless
-    // the model is wide (the WIDE stages do not fit two workgroups per CU together) or MMT_NO_BWD_BOUNDARY=1
+    // MMT_NO_BWD_BOUNDARY=1
     static const bool fuse_boundary = getenv("MMT_NO_BWD_BOUNDARY") == nullptr;
-    const bool boundary = fuse_boundary && L.DP <= 128 && L.NQ <= 512;
+    const bool boundary = fuse_boundary;
     for (int l = D.N - 1; l >= 0; --l) {
         const LayerWs& w = W.lw[l];
         if (l == D.N - 1 || !boundary) {
@@ -635,7 +638,10 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             c4.a = build_qkv(l, dxin);
             c4.a.next_drop = below.a.a_drop; c4.a.next_lda = below.a.KP + 8;      // next A tile = bf16(drop'(dx)), left in LDS
             c4.b = below.a; c4.c = below.b; c4.d = below.c; c4.ldx = 0; c4.lda2 = below.lda2;
-            if ((rc = launch_rowchain(encoder_bwd_boundary_kernel, c4, true, S_BWD_BOUNDARY, "encoder_bwd_boundary_kernel", st, L.DP))) return rc;
+            if (c4.a.no_gs != c4.c.no_gs) { c4.a.no_gs = c4.c.no_gs = 1; }        // (one WIDE flag per kernel: K-chunking alone implies it)
+            if (c4.a.no_gs) rc = launch_rowchain(encoder_bwd_boundary_kernel<true>, c4, true, S_BWD_BOUNDARY, "encoder_bwd_boundary_kernel", st, L.DP);
+            else rc = launch_rowchain(encoder_bwd_boundary_kernel<false>, c4, true, S_BWD_BOUNDARY, "encoder_bwd_boundary_kernel", st, L.DP);
+            if (rc) return rc;
         } else {
             RowGemmParams p = build_qkv(l, dxin);
             if ((rc = launch_rowgemm<EPI_LNBWD, false>(p, st, S_BWD_QKV_LN1))) return rc;

@@ -749,14 +749,15 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
 // and the feed-forward block of layer l-1 opens on the same 32 windows (chain above), in ONE kernel: dx goes to global memory (fp32:
 // the residual gradient of the LayerNorm-2 backward two stages later reads it back — written and read by this workgroup only, with
 // workgroup barriers, each draining the stores, in between) and, dropped and rounded to bf16, straight into the next A tile.  One
-// launch and one staging pass less per layer than `bwd_qkv+ln1` followed by the chain (d_model <= 128; the WIDE stages do not fit
-// two workgroups per CU together).
+// launch and one staging pass less per layer than `bwd_qkv+ln1` followed by the chain.  (WIDE: 83 KB of LDS at d_model = 256, one
+// workgroup per CU — at that width two workgroups sharing a CU take twice as long each anyway)
+template <bool WIDE>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_bwd_boundary_kernel(const RowChain4 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const RowSmem sm = rowchain_carve(smem, ch, true);
+    const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP); warm_weights(ch.d.W, ch.d.NP, ch.d.KP);
-    rowgemm_stage<EPI_LNBWD, false, ASRC_GLOBAL, KEEP_AS>(ch.a, sm);       // layer l:   dx -> global (fp32) + next A tile (bf16, dropped)
+    rowgemm_stage<EPI_LNBWD, false, ASRC_GLOBAL, KEEP_AS, WIDE>(ch.a, sm); // layer l:   dx -> global (fp32) + next A tile (bf16, dropped)
     rowgemm_stage<EPI_PLAIN, false, ASRC_AS, KEEP_A2>(ch.b, sm);           // layer l-1: dh
-    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS>(ch.c, sm);           //            dx1
+    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, WIDE>(ch.c, sm);     //            dx1
     rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0>(ch.d, sm);                  //            dO fragments + delta
 }
