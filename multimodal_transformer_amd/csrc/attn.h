@@ -24,8 +24,10 @@
 // Q/dO/L/delta for the dK-dV kernel) is the same for the four waves, so the workgroup stages it into LDS
 // cooperatively: 2-3 coalesced 16-byte loads per thread, issued one tile AHEAD into registers while the current
 // tile computes, written to the other half of a double buffer, one barrier per tile.  The LDS image keeps the
-// global fragment layouts (lane-linear 16-byte pieces), so every wave's MFMA operand is a conflict-free
-// ds_read_b128.  Register budgets stay near 100-130 VGPRs: 3-5 waves share a SIMD.
+// global fragment layout (R: lane-linear 16-byte pieces), so a wave's MFMA operand for a product that contracts over
+// features is a conflict-free ds_read_b128; operands of products that contract over windows come out of the same
+// tiles through transposing reads (common.h tr_frag2; those tiles keep their 8-feature groups 576 bytes apart).
+// Register budgets stay near 80-130 VGPRs: 3-5 waves share a SIMD.
 template <int NSEG, int MAXL = 3>
 struct TileStager {
     // segment i: `pieces[i]` 16-byte pieces per tile, read from base[i] + tile * stride[i] (bf16 elements); thread t moves pieces

@@ -2,18 +2,20 @@
 //
 // Every window-local step of the encoder (QKV projection, output projection, the two FFN
 // products, their backward input-gradients, embeds, read-out MLPs) is an instance of this kernel.
-// One workgroup (4 waves) owns MMT_ROWS (16) consecutive windows — see "Tile height" below:
+// One workgroup (8 waves) owns MMT_ROWS (32) consecutive windows — see "Tile geometry" below:
 //   1. A tile -> LDS as bf16 [32][KP+8] (optionally through the reference's LayerNorm, computed
 //      in fp32 from an fp32 LDS staging copy; optionally emitting the tile as a row-major bf16
 //      array, an operand of the weight-gradient kernel);
-//   2. per 128-column chunk, wave w multiplies the tile by W rows [n0+32w, n0+32w+32) with
-//      mfma_f32_16x16x32_bf16 (W fragments straight from L2: each is used by exactly one wave,
-//      two k-blocks in flight), and parks its fp32 accumulators in an LDS tile;
+//   2. per 128-column chunk, wave w multiplies the tile by W rows [n0+16w, n0+16w+16) with
+//      mfma_f32_16x16x32_bf16 (W fragments straight from L2 through a small prefetch ring: each is
+//      used by exactly one wave), and parks its fp32 accumulators in an LDS tile;
 //   3. a row-wise epilogue reads that LDS tile with a thread->(row, 4 columns) mapping, so all
 //      global traffic is 8/16-byte coalesced whatever the MFMA accumulator layout was.
 // Epilogues: PLAIN (bias/ReLU/ReLU-mask/residual/row-scale; fp32 and bf16 outputs),
-//            FRAG  (attention operand fragment layouts for Q/K/V or dO, plus delta = rowsum(dO.O)),
+//            FRAG  (attention operand fragment layout (R) for Q/K/V or dO, plus delta = rowsum(dO.O)),
 //            LNBWD (LayerNorm backward fused behind the input-gradient GEMM + residual gradient).
+// Stages chain inside one kernel (the tile stays in LDS between them): the forward chains, the backward chain and the
+// backward boundary chain at the end of this file.
 #pragma once
 #include "common.h"
 
