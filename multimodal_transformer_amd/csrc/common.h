@@ -6,14 +6,13 @@
 //  * matrix products run on bf16 MFMA with fp32 accumulation; the residual stream, LayerNorm
 //    statistics, softmax and every reduction stay fp32.
 //  * "row-major [M][ld]" tensors are indexed by the flattened window index m = b*T + t.
-//  * "T layout" = feature-major copy [feature][MP] (MP = M rounded up to 64, pad columns are zero and
-//    never written) — the operand form the weight-gradient kernel contracts over m.
-//  * attention operands live in two per-(batch,head) *fragment* layouts, chosen so that every MFMA
-//    operand fragment is one lane-linear 16-byte load (1 KiB per wave instruction):
-//      R layout  [tile][e>>3][t&31][e&7]          contraction over the head feature e
-//      T layout  [tile][s][hh][e (32 rows)][j]    contraction over the 32 windows of a tile, in the
-//                 order an MFMA 32x32 accumulator presents its rows:  t&31 = 16 s + 8 (j>>2) + 4 hh + (j&3)
-//    (see cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand").
+//  * every operand exists in memory in ONE layout, window-major: row-major [M][ld] for the GEMM / weight-gradient operands and, for
+//    the attention operands, the per-(batch,head) *fragment* layout
+//      R layout  [tile][e>>3][t&31][e&7]
+//    in which an MFMA operand fragment of a product that contracts over the head feature e is one lane-linear 16-byte load (1 KiB per
+//    wave instruction).  Products that contract over WINDOWS (PV, dV, dK, dQ, the weight gradients) read the same tiles out of LDS
+//    with gfx950's transposing read (tr_frag2 below), in the order an MFMA 32x32 accumulator presents its rows:
+//    t&31 = 16 s + 8 (j>>2) + 4 hh + (j&3)   (see cdna_hip_programming.md 3 "An accumulator tile as the next MFMA's operand").
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

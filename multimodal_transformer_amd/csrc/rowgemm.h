@@ -57,7 +57,6 @@ static_assert(MMT_RTHREADS == 256 || MMT_RTHREADS == 512, "row kernels run 4 or 
 static_assert(MMT_RTHREADS / MMT_ROWS == 8 || MMT_RTHREADS / MMT_ROWS == 16, "8 or 16 threads per row");
 #define MMT_RNW (MMT_RTHREADS / 64)                // waves per workgroup
 #define MMT_RTPR (MMT_RTHREADS / MMT_ROWS)         // threads per row in the row-wise passes (LayerNorm, its backward): 16 or 8
-#define MMT_RG8 (MMT_ROWS / 8)                     // 8-row groups per tile (T-layout copies)
 #define MMT_RSTEP (MMT_RTHREADS / 32)              // row step of the (row, 4 columns) epilogue tasks: rows rbase + RSTEP*it
 #define MMT_RIT (MMT_ROWS / MMT_RSTEP)             // such tasks per thread
 #define MMT_WCOLS (128 / MMT_RNW)                  // columns of a 128-column chunk per wave: 32 (two MFMA tiles) or 16 (one)
