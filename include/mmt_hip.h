@@ -28,7 +28,7 @@ extern "C" {
 
 #define MMT_OK 0
 #define MMT_EINVAL 1      /* bad shape / null pointer */
-#define MMT_EUNSUPPORTED 2 /* e.g. d_k > 32, d % 4 != 0 */
+#define MMT_EUNSUPPORTED 2 /* e.g. d_k > 64, d_model > 512, d % 4 != 0 */
 #define MMT_EWORKSPACE 3  /* workspace too small */
 #define MMT_EHIP 4        /* a HIP runtime call failed */
 
@@ -59,6 +59,9 @@ int mmt_profile_collect(float* total_ms, int* launches);
  * Eval-mode (dropout = identity) when dropout_p == 0; see mmt_encoder_forward's `dropout_p`, `seed`. */
 size_t mmt_encoder_param_count(int d, int f, int n_layers);
 size_t mmt_encoder_workspace_bytes(int B, int T, int d, int h, int f, int n_layers);
+/* ... for calls with dropout_p == 0 only (eval mode): without the attention-dropout bit masks (2 x n_layers x B*h x Tp^2/4 bytes, the
+ * last region of the full workspace: an eval workspace is a prefix of a train one).  A forward and its backward take the same kind. */
+size_t mmt_encoder_workspace_bytes_eval(int B, int T, int d, int h, int f, int n_layers);
 
 int mmt_encoder_forward(const float* x, const float* mask, const float* params, float* y,
                         void* workspace, size_t workspace_bytes,
@@ -91,6 +94,7 @@ int mmt_layernorm_backward(const float* dy, const float* x, const float* a_2, co
  * drawn by the forward into the workspace and re-read by the backward (same dropout_p and seed must be passed); they are
  * dropout stream 0 of mmt_debug_dropout_mask. */
 size_t mmt_sdpa_workspace_bytes(int B, int T, int d, int h);
+size_t mmt_sdpa_workspace_bytes_eval(int B, int T, int d, int h);      /* dropout_p == 0 calls: without the dropout bit masks */
 int mmt_sdpa_forward(const float* q, const float* k, const float* v, const float* mask, float* ctx,
                      void* workspace, size_t workspace_bytes, int B, int T, int d, int h,
                      float dropout_p, uint64_t seed, mmt_stream_t stream);

@@ -26,12 +26,14 @@ SIGNATURES = {
     "mmt_profile_collect": (_I, [_P, _P]),
     "mmt_encoder_param_count": (_SZ, [_I, _I, _I]),
     "mmt_encoder_workspace_bytes": (_SZ, [_I] * 6),
+    "mmt_encoder_workspace_bytes_eval": (_SZ, [_I] * 6),
     "mmt_encoder_forward": (_I, [_P, _P, _P, _P, _P, _SZ] + [_I] * 6 + [_F, _F, _U64, _P]),
     "mmt_encoder_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _SZ] + [_I] * 6 + [_F, _F, _U64, _P]),
     "mmt_layernorm_scratch_floats": (_SZ, [_I, _I]),
     "mmt_layernorm_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "mmt_layernorm_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "mmt_sdpa_workspace_bytes": (_SZ, [_I] * 4),
+    "mmt_sdpa_workspace_bytes_eval": (_SZ, [_I] * 4),
     "mmt_sdpa_forward": (_I, [_P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_F, _U64, _P]),
     "mmt_sdpa_backward": (_I, [_P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_F, _U64, _P]),
     "mmt_linear_workspace_bytes": (_SZ, [_I] * 3),
@@ -156,36 +158,48 @@ POOL = WorkspacePool()
 
 class DeviceErrorWatch:
     """Device error words of asynchronous kernels (today: the exchange time-out of the four-CU LSTM scans,
-    include/mmt_hip.h mmt_lstm_scan_*).  ``watch`` copies the word to pinned host memory behind the launch and records an
-    event; ``poll`` (called at every later launch, never blocking) and ``check`` (blocking) raise if a drained launch left
-    a non-zero word.  Launches captured into a hipGraph are not watched (no host bookkeeping inside a capture)."""
+    include/mmt_hip.h mmt_lstm_scan_*).  ``watch`` copies the word to a pinned host slot behind the launch; ``poll`` (called at
+    every later eager launch, never blocking) and ``check`` (blocking) raise if a drained launch left a non-zero word.
+    Inside a hipGraph capture the copy becomes a node of the graph with a FIXED slot: every replay refreshes it, and ``check``
+    reads those slots too (``poll`` cannot: no event marks the end of a replay).  The pinned ring must exist before a capture
+    starts (pinned allocations are illegal inside one): ``prepare`` makes it, and so does any eager ``watch`` — a warm-up step."""
 
-    SLOTS = 2048                    # ring of pinned host words
+    SLOTS = 2048                    # ring of pinned host words for eager launches
+    GRAPH_SLOTS = 256               # fixed slots of captured launches (never recycled)
 
     def __init__(self):
-        self._pending = []          # (host word, event, description)
+        self._pending = []          # (slot, event, description)
+        self._graph = []            # (slot, description) of captured launches
         self._mutex = threading.Lock()
         self._host = None
         self._next = 0
 
-    def watch(self, dev_word, what):
-        if torch.cuda.is_current_stream_capturing():
-            return                  # no host-side bookkeeping inside a capture: the word still sits at offset 0 of the workspace
+    def prepare(self):
         with self._mutex:
             if self._host is None:
-                self._host = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
-            i, self._next = self._next, (self._next + 1) % self.SLOTS
-            host = self._host[i:i + 1]
-            overflow = len(self._pending) > self.SLOTS - 64     # never let the ring lap an unchecked entry
-        host.copy_(dev_word, non_blocking=True)
+                self._host = torch.zeros(self.SLOTS + self.GRAPH_SLOTS, dtype=torch.int32).pin_memory()
+
+    def watch(self, dev_word, what):
+        if torch.cuda.is_current_stream_capturing():
+            with self._mutex:
+                if self._host is None or len(self._graph) >= self.GRAPH_SLOTS:
+                    return          # no pinned ring yet (nothing ran eagerly before the capture) / table full: this launch stays unwatched
+                slot = self.SLOTS + len(self._graph)
+                self._graph.append((slot, what + " [hipGraph replay]"))
+            self._host[slot:slot + 1].copy_(dev_word, non_blocking=True)         # a memcpy node: refreshed by every replay
+            return
+        self.prepare()
+        with self._mutex:
+            slot, self._next = self._next, (self._next + 1) % self.SLOTS
+            lapped = any(e[0] == slot for e in self._pending)                    # the slot's previous launch has not been looked at yet
+        if lapped:
+            self.check()
+        self._host[slot:slot + 1].copy_(dev_word, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         with self._mutex:
-            self._pending.append((host, ev, what))
-        if overflow:
-            self.check()
-        else:
-            self.poll()
+            self._pending.append((slot, ev, what))
+        self.poll()
 
     @staticmethod
     def _raise(what):
@@ -198,17 +212,22 @@ class DeviceErrorWatch:
             for e in self._pending:
                 (done if e[1].query() else rest).append(e)
             self._pending = rest
-        for host, _, what in done:
-            if int(host[0]) != 0:
+        for slot, _, what in done:
+            if int(self._host[slot]) != 0:
                 self._raise(what)
 
     def check(self):
-        """Synchronise the device and raise if any watched launch (eager or replayed from a graph) reported an error."""
+        """Synchronise the device and raise if any watched launch — eager, or captured and replayed from a hipGraph — reported an error."""
         torch.cuda.synchronize()
         with self._mutex:
             entries, self._pending = self._pending, []
-        for host, _, what in entries:
-            if int(host[0]) != 0:
+            graph = list(self._graph)
+        for slot, _, what in entries:
+            if int(self._host[slot]) != 0:
+                self._raise(what)
+        for slot, what in graph:
+            if int(self._host[slot]) != 0:
+                self._host[slot] = 0
                 self._raise(what)
 
 

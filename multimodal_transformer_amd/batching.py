@@ -78,21 +78,30 @@ def generate_train_batches(data, target, lengths, batch_size=25, device=None):
         yield make_batch(padded, tgt, lengths, index=range(lo, min(lo + batch_size, n)), device=device)
 
 
-def evaluate(model, data, target, lengths, batch_size=25, device=None):
+def evaluate(model, data, target, lengths, batch_size=1, device=None):
     """Mean and spread of the per-sequence CCC and the loss per window, as ``evaluate`` reports them
-    (transformer/SFT/train.py:196-254; the reference walks one sequence at a time, here whole batches run and the CCC of every
-    sequence is reduced on the device).  Sequences shorter than 2 windows have no CCC and are left out of the mean."""
+    (transformer/SFT/train.py:196-254).  The reference evaluates ONE sequence at a time (``batch_size=1``, ``:210-214``), and that
+    is the default here, because it matters: the reference's mask blanks query rows only and never masks keys
+    (SFT/multiTransformer.py:29-30), so in a padded batch every shorter sequence attends to the padding windows (whose keys and
+    values are non-zero after the embed bias and LayerNorm) and its valence differs from the one-at-a-time result.  A larger
+    ``batch_size`` is faster and gives the reference's numbers only when the sequences of a batch have equal length.
+    The loss comes from the fused loss kernel (``mmt_mse_sum_forward``), the CCC of every sequence is reduced on the device
+    (``mmt_ccc_forward``); sequences shorter than 2 windows have no CCC and are left out of the mean (the reference's NaN)."""
     from . import metrics
-    cccs, loss, nwin = [], 0.0, 0
+    from .functional import mse_sum_loss
+    cccs, losses, nwin = [], [], 0
     was_training = model.training
     model.eval()
     with torch.no_grad():
         for d, tg, mask, ls in generate_train_batches(data, target, lengths, batch_size, device):
             out = model(d, ls, mask)
-            loss += float(((out - tg) ** 2).sum())
+            losses.append(mse_sum_loss(out, tg, 1.0))           # stays on the device: one host read-back at the end
             nwin += sum(ls)
             c = metrics.batched_ccc(out, tg, ls)
-            cccs += [float(v) for v, L in zip(c.tolist(), ls) if L > 1]
+            cccs.append((c, ls))
     model.train(was_training)
-    return {"loss": loss / max(nwin, 1), "ccc": float(np.mean(cccs)) if cccs else float("nan"),
-            "ccc_std": float(np.std(cccs)) if cccs else float("nan"), "max_ccc": max(cccs) if cccs else float("nan")}
+    loss = float(torch.stack(losses).double().sum()) if losses else 0.0
+    vals = [float(v) for c, ls in cccs for v, L in zip(c.tolist(), ls) if L > 1]
+    return {"loss": loss / max(nwin, 1), "ccc": float(np.mean(vals)) if vals else float("nan"),
+            "ccc_std": float(np.std(vals)) if vals else float("nan"), "max_ccc": max(vals) if vals else float("nan"),
+            "per_sequence_ccc": vals}

@@ -178,7 +178,9 @@ struct EncWs {
     size_t bytes;
 };
 
-static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
+// `train`: with the attention-dropout bit masks (2 orientations x N layers x B*h x Tp^2/4 bytes: 1.9 GB at T=2500, B=25).  They are the
+// LAST region, so an eval-mode workspace is a prefix of a train-mode one and a long-context evaluation never pays for them.
+static void carve_encoder(EncWs& W, const EncDims& D, void* base, bool train = true) {
     Carver c(base);
     const LayerLayout& L = D.L;
     const size_t M = D.M, MP = D.MP, BH = (size_t)D.B * D.h;
@@ -197,12 +199,6 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
         w.dx2 = c.take<bf16>(MP * L.DP); w.dh = c.take<bf16>(MP * L.FP);
         w.dx1 = c.take<bf16>(MP * L.DP); w.dqkv = c.take<bf16>(MP * L.NQ);
     }
-    {   // attention-dropout bit masks: [layer][bh][tile][tile][32 words], both orientations, written by ONE generator launch
-        const size_t lw = attn_mask_layer_words(D.B * D.h, D.nt);
-        uint16_t* mq = c.take<uint16_t>(lw * (size_t)(D.N > 0 ? D.N : 1));
-        uint16_t* mk = c.take<uint16_t>(lw * (size_t)(D.N > 0 ? D.N : 1));
-        for (int l = 0; l < D.N; ++l) { W.lw[l].maskQ = mq ? mq + lw * l : nullptr; W.lw[l].maskK = mk ? mk + lw * l : nullptr; }
-    }
     for (int l = 0; l < D.N; ++l) {        // contiguous [layer][2 norms][G][2][DP] so one launch reduces them all
         W.lw[l].lnpart1 = c.take<float>((size_t)D.GR * 2 * L.DP); W.lw[l].lnpart2 = c.take<float>((size_t)D.GR * 2 * L.DP);
     }
@@ -220,6 +216,13 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base) {
         const size_t set_bytes = c.off - before;
         W.slab_stride = set_bytes / sizeof(float);
         for (int l = 1; l < D.N; ++l) c.take<char>(set_bytes);
+    }
+    for (int l = 0; l < D.N; ++l) { W.lw[l].maskQ = nullptr; W.lw[l].maskK = nullptr; }
+    if (train) {   // attention-dropout bit masks: [layer][bh][tile][tile][32 words], both orientations, written by ONE generator launch
+        const size_t lw = attn_mask_layer_words(D.B * D.h, D.nt);
+        uint16_t* mq = c.take<uint16_t>(lw * (size_t)(D.N > 0 ? D.N : 1));
+        uint16_t* mk = c.take<uint16_t>(lw * (size_t)(D.N > 0 ? D.N : 1));
+        for (int l = 0; l < D.N; ++l) { W.lw[l].maskQ = mq ? mq + lw * l : nullptr; W.lw[l].maskK = mk ? mk + lw * l : nullptr; }
     }
     W.bytes = c.off;
 }
@@ -407,7 +410,13 @@ extern "C" size_t mmt_encoder_param_count(int d, int f, int n_layers) {
 extern "C" size_t mmt_encoder_workspace_bytes(int B, int T, int d, int h, int f, int n_layers) {
     EncDims D;
     if (make_dims(D, B, T, d, h, f, n_layers) != MMT_OK) return 0;
-    EncWs W; carve_encoder(W, D, nullptr);
+    EncWs W; carve_encoder(W, D, nullptr, true);
+    return W.bytes;
+}
+extern "C" size_t mmt_encoder_workspace_bytes_eval(int B, int T, int d, int h, int f, int n_layers) {
+    EncDims D;
+    if (make_dims(D, B, T, d, h, f, n_layers) != MMT_OK) return 0;
+    EncWs W; carve_encoder(W, D, nullptr, false);
     return W.bytes;
 }
 
@@ -423,7 +432,7 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
     if (!x || !mask || !params || !y || !workspace) return fail(MMT_EINVAL, "null pointer argument");
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(MMT_EINVAL, "dropout_p %g not in [0,1)", dropout_p);
     if (dropout_p > 0.f && D.Tp > 4096) return fail(MMT_EUNSUPPORTED, "train-mode dropout supports T <= 4096 (got %d)", T);
-    EncWs W; carve_encoder(W, D, workspace);
+    EncWs W; carve_encoder(W, D, workspace, dropout_p > 0.f);
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const LayerLayout& L = D.L;
@@ -547,7 +556,7 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
     if (rc) return rc;
     if (!dy || !x || !mask || !params || !dx || !dparams || !workspace) return fail(MMT_EINVAL, "null pointer argument");
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(MMT_EINVAL, "dropout_p %g not in [0,1)", dropout_p);
-    EncWs W; carve_encoder(W, D, workspace);
+    EncWs W; carve_encoder(W, D, workspace, dropout_p > 0.f);
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const LayerLayout& L = D.L;
@@ -754,7 +763,7 @@ __global__ void unpad_heads_kernel(const bf16* __restrict__ src, int ld, int col
 }
 
 struct SdpaWs { bf16 *QR, *KR, *VR, *dOR, *ctx, *dqkv; float *lse, *delta; uint16_t *maskQ, *maskK; size_t bytes; };
-static void carve_sdpa(SdpaWs& W, const EncDims& D, void* base) {
+static void carve_sdpa(SdpaWs& W, const EncDims& D, void* base, bool train = true) {
     Carver c(base);
     const LayerLayout& L = D.L;
     const size_t BH = (size_t)D.B * D.h, M = D.M;
@@ -763,8 +772,9 @@ static void carve_sdpa(SdpaWs& W, const EncDims& D, void* base) {
     W.ctx = c.take<bf16>(M * L.HDP);
     W.dqkv = c.take<bf16>(M * L.NQ);
     W.lse = c.take<float>(BH * D.Tp); W.delta = c.take<float>(BH * D.Tp);
-    W.maskQ = c.take<uint16_t>(attn_mask_layer_words(D.B * D.h, D.nt)); W.maskK = c.take<uint16_t>(attn_mask_layer_words(D.B * D.h, D.nt));
-    W.bytes = c.off;
+    W.maskQ = W.maskK = nullptr;
+    if (train) { W.maskQ = c.take<uint16_t>(attn_mask_layer_words(D.B * D.h, D.nt)); W.maskK = c.take<uint16_t>(attn_mask_layer_words(D.B * D.h, D.nt)); }
+    W.bytes = c.off;       // the dropout bit masks are the last region: an eval-mode workspace is a prefix of a train-mode one
 }
 
 static int check_drop(float dropout_p, const EncDims& D) {
@@ -776,7 +786,13 @@ static int check_drop(float dropout_p, const EncDims& D) {
 extern "C" size_t mmt_sdpa_workspace_bytes(int B, int T, int d, int h) {
     EncDims D;
     if (make_dims(D, B, T, d, h, 4, 0) != MMT_OK) return 0;
-    SdpaWs W; carve_sdpa(W, D, nullptr);
+    SdpaWs W; carve_sdpa(W, D, nullptr, true);
+    return W.bytes;
+}
+extern "C" size_t mmt_sdpa_workspace_bytes_eval(int B, int T, int d, int h) {
+    EncDims D;
+    if (make_dims(D, B, T, d, h, 4, 0) != MMT_OK) return 0;
+    SdpaWs W; carve_sdpa(W, D, nullptr, false);
     return W.bytes;
 }
 
@@ -788,7 +804,7 @@ extern "C" int mmt_sdpa_forward(const float* q, const float* k, const float* v, 
     if (rc) return rc;
     if (!q || !k || !v || !ctx || !workspace) return fail(MMT_EINVAL, "null pointer argument");
     if ((rc = check_drop(dropout_p, D))) return rc;
-    SdpaWs W; carve_sdpa(W, D, workspace);
+    SdpaWs W; carve_sdpa(W, D, workspace, dropout_p > 0.f);
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const LayerLayout& L = D.L;
@@ -813,7 +829,7 @@ extern "C" int mmt_sdpa_backward(const float* dctx, const float* mask, float* dq
     if (rc) return rc;
     if (!dctx || !dq || !dk || !dv || !workspace) return fail(MMT_EINVAL, "null pointer argument");
     if ((rc = check_drop(dropout_p, D))) return rc;
-    SdpaWs W; carve_sdpa(W, D, workspace);
+    SdpaWs W; carve_sdpa(W, D, workspace, dropout_p > 0.f);
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const LayerLayout& L = D.L;
@@ -986,6 +1002,15 @@ template <typename K> static bool cl4_resident(K kernel, int grid) {
     return (long)per_cu * cus >= 2L * grid;
 }
 
+// ... evaluated once per (device, kernel): the answer depends on the device that is current, not on the first one that asked
+template <typename K> static int cl4_fits(K kernel, int which) {
+    static int cache[2][64];                    // 0: unknown, 1: no, 2: yes
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return cl4_resident(kernel, 128) ? 1 : 0;
+    if (!cache[which][dev]) cache[which][dev] = cl4_resident(kernel, 128) ? 2 : 1;     // 128: the largest grid this path launches
+    return cache[which][dev] == 2;
+}
+
 // sequences per scan workgroup: the smallest power of two that still fits the batch into <= 256 workgroups (one per CU)
 static int scan_bt(int B) { int bt = 1; while (bt < 16 && (B + bt - 1) / bt > 256) bt *= 2; return bt; }
 
@@ -1012,7 +1037,7 @@ extern "C" int mmt_lstm_scan_forward(const float* gx, const float* W_rec, const 
         gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, BT)
     static const bool no_cluster = getenv("MMT_NO_CLUSTER_SCAN") != nullptr;
     const int cl_grid = 32 * ((B + 7) / 8);
-    static const int cl_fit = cl4_resident(&lstm_scan_fwd_cl4_kernel<3>, 128) ? 1 : 0;        // the largest grid this path launches
+    const int cl_fit = cl4_fits(&lstm_scan_fwd_cl4_kernel<3>, 0);
     const bool cluster = W.HPAD == 256 && B <= 32 && !no_cluster && cl_fit;
     HIP_TRY(hipMemsetAsync(W.err, 0, MMT_SCAN_ERR_BYTES + (cluster ? W.xb_bytes : 0), st));    // error word (+ exchange granules)
     if (cluster) {       // four CUs per sequence, weights fully register-resident (scan_cluster.h)
@@ -1060,7 +1085,7 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
 #define MMT_LSTM_BWD(KS4, NT, WREG, PF, COOP) hipLaunchKernelGGL((lstm_scan_bwd_kernel<KS4, NT, WREG, PF, COOP>), grid, block, lds, st, \
         dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, BT)
     static const bool no_cluster = getenv("MMT_NO_CLUSTER_SCAN") != nullptr;
-    static const int cl_fit = cl4_resident(&lstm_scan_bwd_cl4_kernel<2>, 128) ? 1 : 0;
+    const int cl_fit = cl4_fits(&lstm_scan_bwd_cl4_kernel<2>, 1);
     const bool cluster = W.HPAD == 256 && B <= 32 && !no_cluster && cl_fit;
     HIP_TRY(hipMemsetAsync(W.err, 0, MMT_SCAN_ERR_BYTES + (cluster ? W.xb_bytes : 0), st));
     if (cluster) {
@@ -1238,6 +1263,8 @@ extern "C" int mmt_mse_sum_forward(const float* pred, const float* target, float
                                    size_t n, mmt_stream_t stream) {
     if (!pred || !target || !loss || !dpred || !scratch) return fail(MMT_EINVAL, "null pointer argument");
     if (n == 0) return fail(MMT_EINVAL, "empty loss");
+    if ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(dpred)) & 15)
+        return fail(MMT_EINVAL, "mse_sum: pred, target and dpred must be 16-byte aligned (the kernel moves four floats per lane)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int g = grid_for(n, 1024);
     hipLaunchKernelGGL(mse_sum_partial_kernel, dim3(g), dim3(256), 0, st, pred, target, inv_denom, dpred, scratch, n);
@@ -1253,7 +1280,9 @@ extern "C" int mmt_adam_step(float* const* params, const float* const* grads, fl
     if (!params || !grads || !exp_avg || !exp_avg_sq || !counts) return fail(MMT_EINVAL, "null pointer argument");
     if (nchunks <= 0 || step <= 0) return fail(MMT_EINVAL, "adam: nchunks %d, step %d must be positive", nchunks, step);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    // bias corrections in double, as torch.optim.Adam takes them (python floats): step_size = lr / (1 - beta1^t), sqrt(1 - beta2^t)
+    const float step_size = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
+    const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     for (int c0 = 0; c0 < nchunks; c0 += MMT_ADAM_MAX_CHUNKS) {
         AdamChunks C; memset(&C, 0, sizeof(C));
         const int nc = std::min(MMT_ADAM_MAX_CHUNKS, nchunks - c0);
@@ -1264,7 +1293,7 @@ extern "C" int mmt_adam_step(float* const* params, const float* const* grads, fl
             nmax = std::max(nmax, counts[c0 + c]);
         }
         const int gx = (int)std::min<size_t>(512, (nmax + 1023) / 1024);
-        hipLaunchKernelGGL(adam_step_kernel, dim3(gx > 0 ? gx : 1, nc), dim3(256), 0, st, C, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+        hipLaunchKernelGGL(adam_step_kernel, dim3(gx > 0 ? gx : 1, nc), dim3(256), 0, st, C, step_size, beta1, beta2, eps, weight_decay, bc2s);
         LAUNCH_CHECK("adam_step_kernel");
     }
     return MMT_OK;

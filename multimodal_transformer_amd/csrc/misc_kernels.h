@@ -518,12 +518,11 @@ __global__ __launch_bounds__(256) void mse_sum_final_kernel(const double* __rest
 #define MMT_ADAM_MAX_CHUNKS 48
 struct AdamChunks { float* p[MMT_ADAM_MAX_CHUNKS]; const float* g[MMT_ADAM_MAX_CHUNKS]; float* m[MMT_ADAM_MAX_CHUNKS]; float* v[MMT_ADAM_MAX_CHUNKS];
                     unsigned long long n[MMT_ADAM_MAX_CHUNKS]; };
-__global__ __launch_bounds__(256) void adam_step_kernel(const AdamChunks C, float lr, float beta1, float beta2, float eps, float wd,
-                                                        float bc1, float bc2_sqrt) {       // bc1 = 1 - beta1^t, bc2_sqrt = sqrt(1 - beta2^t)
+__global__ __launch_bounds__(256) void adam_step_kernel(const AdamChunks C, float step, float beta1, float beta2, float eps, float wd,
+                                                        float bc2_sqrt) {       // step = lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t): taken in double on the host, like torch
     const int c = blockIdx.y;
     float* __restrict__ p = C.p[c]; const float* __restrict__ g = C.g[c]; float* __restrict__ m = C.m[c]; float* __restrict__ v = C.v[c];
     const size_t n = C.n[c];
-    const float step = lr / bc1;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float pi = p[i];
         const float gi = g[i] + wd * pi;                          // grad = grad.add(param, alpha=weight_decay)

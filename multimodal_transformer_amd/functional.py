@@ -16,6 +16,12 @@ def _f32c(t):
     return t.detach().contiguous().float() if t is not None else None
 
 
+def _f32c16(t):
+    """contiguous fp32 AND 16-byte aligned (a contiguous view at an odd storage offset is not): for kernels that move four floats per lane"""
+    t = _f32c(t)
+    return t.clone() if t is not None and t.data_ptr() % 16 else t
+
+
 class _EncoderStackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mask, flat_params, h, d_ff, n_layers, eps, dropout_p, seed, _needs=False):
@@ -28,10 +34,11 @@ class _EncoderStackFn(torch.autograd.Function):
         need = lib.mmt_encoder_param_count(d, d_ff, n_layers)
         if p_.numel() != need:
             raise ValueError("flat parameter buffer has %d elements, expected %d" % (p_.numel(), need))
-        nbytes = lib.mmt_encoder_workspace_bytes(B, T, d, h, d_ff, n_layers)
+        train = dropout_p > 0.0                    # eval-mode workspaces carry no dropout bit masks
+        nbytes = (lib.mmt_encoder_workspace_bytes if train else lib.mmt_encoder_workspace_bytes_eval)(B, T, d, h, d_ff, n_layers)
         if nbytes == 0:
             _lib.check(lib.mmt_encoder_forward(None, None, None, None, None, 0, B, T, d, h, d_ff, n_layers, eps, 0.0, 0, None))
-        ws = _lib.POOL.get(nbytes, x_.device, tag=("encoder", B, T, d, h, d_ff, n_layers))
+        ws = _lib.POOL.get(nbytes, x_.device, tag=("encoder", B, T, d, h, d_ff, n_layers, train))
         y = torch.empty_like(x_)
         _lib.check(lib.mmt_encoder_forward(_lib.ptr(x_), _lib.ptr(m_), _lib.ptr(p_), _lib.ptr(y), _lib.ptr(ws), nbytes,
                                            B, T, d, h, d_ff, n_layers, eps, dropout_p, seed, _lib.stream_ptr()))
@@ -155,10 +162,11 @@ class _SdpaFn(torch.autograd.Function):
             raise NotImplementedError("sdpa: query, key and value must share the shape (B,T,d)")
         if m_ is not None and m_.numel() != B * T:
             raise NotImplementedError("sdpa: only the reference's query-row mask of shape (B,T,1) is supported")
-        nbytes = lib.mmt_sdpa_workspace_bytes(B, T, d, h)
+        train = dropout_p > 0.0
+        nbytes = (lib.mmt_sdpa_workspace_bytes if train else lib.mmt_sdpa_workspace_bytes_eval)(B, T, d, h)
         if nbytes == 0:
             _lib.check(lib.mmt_sdpa_forward(None, None, None, None, None, None, 0, B, T, d, h, 0.0, 0, None))
-        ws = _lib.POOL.get(nbytes, q_.device, tag=("sdpa", B, T, d, h))
+        ws = _lib.POOL.get(nbytes, q_.device, tag=("sdpa", B, T, d, h, train))
         out = torch.empty_like(q_)
         _lib.check(lib.mmt_sdpa_forward(_lib.ptr(q_), _lib.ptr(k_), _lib.ptr(v_), _lib.ptr(m_), _lib.ptr(out), _lib.ptr(ws), nbytes,
                                         B, T, d, h, dropout_p, seed, _lib.stream_ptr()))
@@ -424,7 +432,7 @@ class _MseSumLossFn(torch.autograd.Function):
     def forward(ctx, pred, target, denom):
         lib = _lib.load()
         _lib.require_hip(pred, target)
-        p_, t_ = _f32c(pred), _f32c(target)
+        p_, t_ = _f32c16(pred), _f32c16(target)
         if p_.shape != t_.shape:
             raise ValueError("mse_sum_loss: pred %s and target %s differ in shape" % (tuple(pred.shape), tuple(target.shape)))
         n = p_.numel()
@@ -453,7 +461,7 @@ def mse_sum_loss_backward(pred, target, denom):
     handed straight to ``pred.backward``.  Returns the detached loss."""
     lib = _lib.load()
     _lib.require_hip(pred, target)
-    p_, t_ = _f32c(pred), _f32c(target)
+    p_, t_ = _f32c16(pred), _f32c16(target)
     if p_.shape != t_.shape:
         raise ValueError("mse_sum_loss: pred %s and target %s differ in shape" % (tuple(pred.shape), tuple(target.shape)))
     n = p_.numel()

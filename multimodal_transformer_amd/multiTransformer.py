@@ -157,6 +157,7 @@ class Encoder(nn.Module):
         self.layers = clones(layer, N)
         self.norm = LayerNorm(layer.size)
         self._flat = None        # one buffer holding every parameter of the stack in the library's order; the Parameters are views of it
+        self._flat_sig = None    # data pointers of the 16 N + 2 parameters while they are such views
 
     def _apply(self, fn, *args, **kwargs):        # .to() / .cuda() / .float() replace the parameters' storage
         self._flat = None
@@ -165,9 +166,11 @@ class Encoder(nn.Module):
     def _flat_storage(self, ps):
         """The fused stack reads its 16 N + 2 parameter tensors as ONE flat fp32 buffer.  Concatenating them costs a kernel per step, so the
         Parameters are re-seated once as views of such a buffer (like ``nn.LSTM.flatten_parameters``): optimizers and ``load_state_dict``
-        update them in place and the buffer follows.  Anything that replaces a parameter's storage is detected by the pointer check."""
+        update them in place and the buffer follows.  Anything that replaces the storage of ANY parameter (``w.data = ...``, pruning or
+        re-initialisation utilities, ``load_state_dict(assign=True)``) is detected by the signature of all 16 N + 2 pointers, the same
+        check ``optim.FlatAdam`` makes, and the buffer is rebuilt."""
         flat = self._flat
-        if flat is not None and ps[0].data_ptr() == flat.data_ptr() and ps[-1].data_ptr() == flat.data_ptr() + 4 * (flat.numel() - ps[-1].numel()):
+        if flat is not None and tuple(q.data_ptr() for q in ps) == self._flat_sig:
             return flat
         dev = ps[0].device
         if torch.cuda.is_current_stream_capturing() or any(q.device != dev or q.dtype != torch.float32 or not q.is_contiguous() for q in ps):
@@ -181,6 +184,7 @@ class Encoder(nn.Module):
                 q.data = view
                 off += q.numel()
         self._flat = flat
+        self._flat_sig = tuple(q.data_ptr() for q in ps)
         return flat
 
     def _fusable(self):

@@ -26,7 +26,9 @@ RELU_GRAD_RTOL = 9e-2
 CCC_MIN = 1 - 1e-3
 
 FULL = {
+    "C2": dict(B=32, T=300, d=40, h=4, N=6),          # configs[1]: d_k = 10 (a padded head), T in the one-kernel-backward range
     "C4": dict(B=32, T=500, d=128, h=8, N=6),
+    "C4x8": dict(B=256, T=500, d=128, h=8, N=6),      # configs[3] WHOLE batch on one GPU (bench.py's config_full_batch line)
     "C5e": dict(B=16, T=1000, d=256, h=8, N=6),       # 16 of the 64 sequences/GPU of configs[4]: same T, d, h, N
 }
 
@@ -170,7 +172,7 @@ def _check_sequences(name, model_out, oracle_fn, lengths, picks):
         ccc = eval_ccc(ref[:L].reshape(-1), got[:L].reshape(-1)) if L > 2 else 1.0
         print("%s seq %d (len %d): valence rel_l2 %.3e  CCC %.6f" % (name, b, L, r, ccc))
         cccs.append(ccc)
-        assert r < OUT_RTOL and ccc >= 1 - 2e-3
+        assert r < OUT_RTOL and ccc >= CCC_MIN         # north_star: valence CCC within 1e-3 of the CPU reference, per sequence
     # the reference's metric is the MEAN of per-sequence CCCs (transformer/SFT/train.py evaluate()); a random-init model
     # has a nearly flat valence track (std ~1e-2), the least favourable case for a correlation measure
     assert float(np.mean(cccs)) >= CCC_MIN

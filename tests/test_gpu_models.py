@@ -289,7 +289,10 @@ def test_batched_ccc_on_device(dev):
 
 
 def test_evaluate_loop_matches_per_sequence_oracle(dev):
-    """batching.evaluate: batches through the SFT model + device CCC = mean of per-sequence CCCs of the oracle's valence"""
+    """batching.evaluate with its default batch_size=1 (the reference's evaluation, transformer/SFT/train.py:210-214): per-sequence
+    CCC, their mean and the loss per window equal the oracle's on the UNPADDED sequences.  Then the reason for that default is
+    pinned: in a padded batch the shorter sequences attend to the padding windows (keys are never masked, SFT/multiTransformer.py:29-30),
+    the HIP path reproduces that too (parity with the oracle on the same padded batch), and the result is far from the unpadded one."""
     from multimodal_transformer_amd import batching
     MT = mta().multiTransformer
     model = MT.NLPTransformer(512, embed_dim=40, h=4, N=2, device=dev)
@@ -308,9 +311,25 @@ def test_evaluate_loop_matches_per_sequence_oracle(dev):
         def forward(self, data, lengths, mask):
             return self.m(data["fused"], mask, lengths)
 
-    stats = batching.evaluate(Wrap(model), {"fused": x.numpy()}, tgt.numpy(), lengths, batch_size=3, device=dev)
-    cccs = []
+    stats = batching.evaluate(Wrap(model), {"fused": x.numpy()}, tgt.numpy(), lengths, device=dev)
+    cccs, sq, unpadded = [], 0.0, {}
     for i, L in enumerate(lengths):
         yo = oracle.nlp_transformer(p32, x[i:i + 1, :L], R.prefix_mask([L], L), 4)[0, :, 0].detach().numpy()
-        cccs.append(mta().eval_ccc(yo, tgt[i, :L].numpy()))
-    assert abs(stats["ccc"] - float(np.mean(cccs))) < 2e-3
+        unpadded[i] = yo
+        sq += float(((yo - tgt[i, :L].numpy()) ** 2).sum())
+        if L > 1:
+            cccs.append(mta().eval_ccc(yo, tgt[i, :L].numpy()))
+    assert len(stats["per_sequence_ccc"]) == len(cccs)
+    for a, b in zip(stats["per_sequence_ccc"], cccs):    # batch_size=1: evaluation order = input order
+        assert abs(a - b) < 2e-3, (a, b)
+    assert abs(stats["ccc"] - float(np.mean(cccs))) < 1e-3
+    assert abs(stats["loss"] - sq / sum(lengths)) < 2e-2 * sq / sum(lengths)
+    # a padded batch: parity with the oracle on the SAME padded batch, and a visibly different valence for the shorter sequences
+    mask3 = R.prefix_mask(lengths[:3], T)
+    with torch.no_grad():
+        got = model(x[:3].to(dev), mask3.to(dev), lengths[:3]).cpu().numpy()
+    ref = oracle.nlp_transformer(p32, x[:3], mask3, 4).detach().numpy()
+    assert rel_l2(got, ref) < 2e-2
+    for i in (1, 2):
+        L = lengths[i]
+        assert rel_l2(got[i, :L, 0], unpadded[i]) > 0.2, "padding windows are keys of the shorter sequences in the reference"
