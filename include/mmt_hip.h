@@ -76,6 +76,22 @@ int mmt_encoder_backward(const float* dy, const float* x, const float* mask, con
                          int B, int T, int d, int h, int f, int n_layers, float eps,
                          float dropout_p, uint64_t seed, mmt_stream_t stream);
 
+/* Device-resident dropout seed: the same pair for a step that is captured into a hipGraph and replayed, where a seed passed by value
+ * would be frozen at capture (the reference's nn.Dropout draws fresh masks every step: transformer/MFT/multiTransformer.py:17,45,101,
+ * torch keeps its generator state on the device under graph capture for the same reason).  `seed_state`: one uint64 in device memory,
+ * owned by the caller.  The forward's first kernel copies it into the workspace (the seed of THIS forward and of its backward) and
+ * advances it (splitmix64), so every replay draws new masks; the masks of a step are those mmt_debug_dropout_mask gives for the value
+ * seed_state held before that step.  The backward takes no seed: it reads the workspace. */
+int mmt_encoder_forward_devseed(const float* x, const float* mask, const float* params, float* y,
+                                void* workspace, size_t workspace_bytes,
+                                int B, int T, int d, int h, int f, int n_layers, float eps,
+                                float dropout_p, uint64_t* seed_state, mmt_stream_t stream);
+int mmt_encoder_backward_devseed(const float* dy, const float* x, const float* mask, const float* params,
+                                 float* dx, float* dparams,
+                                 void* workspace, size_t workspace_bytes,
+                                 int B, int T, int d, int h, int f, int n_layers, float eps,
+                                 float dropout_p, mmt_stream_t stream);
+
 /* ---- LayerNorm alone.  Replaces LayerNorm.forward            transformer/MFT/multiTransformer.py:88-91
  * stats: (M,2) fp32 scratch kept for the backward (mean, 1/(std+eps)).
  * colpart: scratch of mmt_layernorm_scratch_floats(M,d) floats. */
@@ -145,6 +161,10 @@ size_t mmt_mfn_mem_scan_workspace_bytes(void);
 int mmt_mfn_mem_scan_forward(const float* apre, const float* chat, const float* Wm, const float* W2, const float* b2,
                              float* mem_all, float* u_all, float* g_all, void* workspace, size_t workspace_bytes,
                              int T, int B, int mem_dim, int h_gamma, float dropout_p, uint64_t seed, mmt_stream_t stream);
+/* the same with a device-resident seed (see mmt_encoder_forward_devseed); the backward needs none (u_all keeps the dropped values) */
+int mmt_mfn_mem_scan_forward_devseed(const float* apre, const float* chat, const float* Wm, const float* W2, const float* b2,
+                                     float* mem_all, float* u_all, float* g_all, void* workspace, size_t workspace_bytes,
+                                     int T, int B, int mem_dim, int h_gamma, float dropout_p, uint64_t* seed_state, mmt_stream_t stream);
 /* dmem_all (T,B,128) or NULL -> dchat (T,B,128), dapre (T,B,128), dz_all (T,B,256) (pre-sigmoid gate gradients). */
 int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* chat, const float* mem_all, const float* u_all,
                               const float* g_all, const float* Wm, const float* W2,

@@ -29,6 +29,8 @@ SIGNATURES = {
     "mmt_encoder_workspace_bytes_eval": (_SZ, [_I] * 6),
     "mmt_encoder_forward": (_I, [_P, _P, _P, _P, _P, _SZ] + [_I] * 6 + [_F, _F, _U64, _P]),
     "mmt_encoder_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _SZ] + [_I] * 6 + [_F, _F, _U64, _P]),
+    "mmt_encoder_forward_devseed": (_I, [_P, _P, _P, _P, _P, _SZ] + [_I] * 6 + [_F, _F, _P, _P]),
+    "mmt_encoder_backward_devseed": (_I, [_P, _P, _P, _P, _P, _P, _P, _SZ] + [_I] * 6 + [_F, _F, _P]),
     "mmt_layernorm_scratch_floats": (_SZ, [_I, _I]),
     "mmt_layernorm_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "mmt_layernorm_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
@@ -44,6 +46,7 @@ SIGNATURES = {
     "mmt_lstm_scan_backward": (_I, [_P] * 10 + [_SZ] + [_I] * 3 + [_P]),
     "mmt_mfn_mem_scan_workspace_bytes": (_SZ, []),
     "mmt_mfn_mem_scan_forward": (_I, [_P] * 9 + [_SZ] + [_I] * 4 + [_F, _U64, _P]),
+    "mmt_mfn_mem_scan_forward_devseed": (_I, [_P] * 9 + [_SZ] + [_I] * 4 + [_F, _P, _P]),
     "mmt_mfn_mem_scan_backward": (_I, [_P] * 11 + [_SZ] + [_I] * 4 + [_F, _P]),
     "mmt_convpool_workspace_bytes": (_SZ, [_I] * 4),
     "mmt_convpool_forward": (_I, [_P] * 6 + [_SZ] + [_I] * 4 + [_P]),
@@ -247,13 +250,23 @@ def mix64(*words):
     return z & 0x7FFFFFFFFFFFFFFF
 
 
-def next_dropout_seed(device, site):
-    """Seed of one train-mode forward of one module.  Like torch's own dropout kernels it is drawn from the DEVICE generator
-    (seed, offset) and advances the offset, so: every call of every module instance gets fresh masks (the three modality
-    encoders of the MFT no longer share them), a run restored with its RNG state continues its mask sequence instead of
-    replaying it from step 1, and torch.manual_seed() controls it.  The data-parallel rank is mixed in: ranks seeded alike
-    still drop different units.  During hipGraph capture the generator cannot be advanced on the host; a
-    process-wide counter stands in (the captured seed is frozen under replay anyway: bench only)."""
+class DeviceSeed:
+    """A 64-bit dropout seed that lives in device memory (include/mmt_hip.h mmt_encoder_forward_devseed): the forward's first kernel
+    reads it, leaves it in the workspace for its backward and advances it, so a training step replayed from a hipGraph draws fresh
+    masks at every replay — a seed passed by value would be frozen at capture.  ``peek()`` = the seed the NEXT forward will use
+    (``functional.dropout_mask(p, seed, stream, ...)`` replays that step's masks)."""
+
+    def __init__(self, device, value):
+        self.state = torch.tensor([int(value) & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device)
+
+    def peek(self):
+        return int(self.state.item()) & 0xFFFFFFFFFFFFFFFF
+
+    def ptr(self):
+        return self.state.data_ptr()
+
+
+def _host_seed(device, site):
     rank = 0
     try:
         import torch.distributed as dist
@@ -273,6 +286,33 @@ def next_dropout_seed(device, site):
         _seed_fallback_counter[0] += 1
         off = (1 << 40) + _seed_fallback_counter[0]
     return mix64(base, off, rank, site)
+
+
+def next_dropout_seed(device, site, holder=None):
+    """Seed of one train-mode forward of one module.
+
+    Eager launches: a python int drawn, like torch's own dropout kernels, from the DEVICE generator (seed, offset), advancing the offset:
+    every call of every module instance gets fresh masks, a run restored with its RNG state continues its mask sequence, and
+    torch.manual_seed() controls it.  The data-parallel rank is mixed in: ranks seeded alike still drop different units.
+
+    During hipGraph capture (or with MMT_DEVICE_SEED=1): the module's ``DeviceSeed`` — a seed in device memory that the captured
+    kernels read and advance, so every REPLAY draws new masks.  It is created at the module's first eager train-mode call (seeded
+    from the generator as above); capturing a module that never ran eagerly raises (a warm-up step always precedes a capture)."""
+    capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    if holder is not None:
+        ds = holder.__dict__.get("_dev_seed")
+        if ds is None or ds.state.device != device:
+            if capturing:
+                raise RuntimeError("hipGraph capture of a train-mode %s before its first eager call: run one warm-up step so that its "
+                                   "device-resident dropout seed exists" % type(holder).__name__)
+            ds = DeviceSeed(device, _host_seed(device, site))
+            holder.__dict__["_dev_seed"] = ds
+        if capturing or os.environ.get("MMT_DEVICE_SEED") == "1":
+            return ds
+    elif capturing:
+        _seed_fallback_counter[0] += 1
+        return mix64(torch.initial_seed(), (1 << 40) + _seed_fallback_counter[0], site)     # frozen under replay: stand-alone attention() only
+    return _host_seed(device, site)
 
 
 def profile(on):

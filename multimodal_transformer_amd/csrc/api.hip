@@ -13,7 +13,7 @@
 #include "rowgemm.h"
 #include "attn_mask.h"
 #include "attn.h"
-#include "attn_bwd_fused.h"
+#include "attn_bwd_diag.h"
 #include "misc_kernels.h"
 #include "scan.h"
 #include "scan256.h"
@@ -44,7 +44,7 @@ static const char* const g_site_names[S_COUNT] = {
     "attn_bwd_dq_kernel", "rowgemm<LNBWD>:bwd_qkv+ln1", "wgrad_kernel", "finalize_kernels", "other",
     "rowgemm<PLAIN>:linear_fwd", "rowgemm<PLAIN>:linear_bwd_dx", "wgrad_kernel:linear", "lstm_scan_fwd_kernel", "lstm_scan_bwd_kernel",
     "mfn_mem_scan_fwd_kernel", "mfn_mem_scan_bwd_kernel", "convpool_fwd_kernel", "convpool_bwd_kernel",
-    "chain:outproj+res>ln2+ffn1>ffn2+res>ln1+qkv(next)", "attn_bwd_fused16_kernel", "attn_mask_gen_kernel",
+    "chain:outproj+res>ln2+ffn1>ffn2+res>ln1+qkv(next)", "attn_bwd_diag16_kernel", "attn_mask_gen_kernel",
     "chain:bwd_qkv+ln1>bwd_ffn2(below)>bwd_ffn1+ln2>bwd_outproj->dO"};
 struct ProfRec { int site; hipEvent_t a, b; };
 static bool g_prof = false;
@@ -168,6 +168,7 @@ struct LayerWs {
     uint16_t *maskQ, *maskK;                // attention-dropout lane words of this layer (attn_mask.h)
 };
 struct EncWs {
+    uint64_t* seedword;                      // device-resident dropout seed of the forward that last used this workspace (256-byte slot)
     bf16* wprep; float* bprep; float* statsf;
     LayerWs lw[MAX_LAYERS];
     // backward scratch (shared by all layers; single stream)
@@ -184,6 +185,7 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base, bool train = t
     Carver c(base);
     const LayerLayout& L = D.L;
     const size_t M = D.M, MP = D.MP, BH = (size_t)D.B * D.h;
+    W.seedword = c.take<uint64_t>(1);
     W.wprep = c.take<bf16>(L.pstride() * (size_t)(D.N > 0 ? D.N : 1));
     W.bprep = c.take<float>(L.qstride() * (size_t)(D.N > 0 ? D.N : 1));
     W.statsf = c.take<float>(2 * M);
@@ -286,15 +288,25 @@ static int launch_rowchain(K kernel, CH& ch, bool lnbwd, int site, const char* n
 static RowGemmParams rg_zero() { RowGemmParams p; memset(&p, 0, sizeof(p)); p.mask_scale = 1.0f; return p; }
 
 static DropCfg no_drop() { return make_drop(0.f, 0, 0); }
+// Dropout configuration of one stream: keys mixed on the host from a by-value seed, or — device-resident seed (`devseed`) — the stream id
+// in s0 for the kernels to resolve against the workspace's seed word (common.h drop_resolve)
+#define MMT_ATTN_DROP_BITS 12         // resolution of the attention-probability dropout (common.h make_drop)
+static DropCfg stream_drop(float p, uint64_t seed, uint32_t stream, bool devseed, int bits = 16) {
+    DropCfg c = make_drop(p, seed, stream, bits);
+    if (devseed) { c.s0 = stream; c.s1 = 0; }
+    return c;
+}
 
 // Attention-probability dropout of `nlayers` layers: ONE launch draws every decision (stream 4l+0 of layer l) into the lane-mask
 // arrays mq / mk (layer l at + l * attn_mask_layer_words).  attn_mask.h.
-static int fill_mask_gen(MaskGenParams& P, uint16_t* mq, uint16_t* mk, const EncDims& D, int nlayers, float p, uint64_t seed) {
+static int fill_mask_gen(MaskGenParams& P, uint16_t* mq, uint16_t* mk, const EncDims& D, int nlayers, float p, uint64_t seed,
+                         const uint64_t* seedword = nullptr) {
     if (nlayers > 16) return fail(MMT_EUNSUPPORTED, "mask generator: %d layers > 16", nlayers);
     memset(&P, 0, sizeof(P));
     P.lq = mq; P.lk = mk; P.nbh = D.B * D.h; P.nt = D.nt; P.nlayers = nlayers;
     P.layer_words = attn_mask_layer_words(P.nbh, P.nt);
-    for (int l = 0; l < nlayers; ++l) { const DropCfg c = make_drop(p, seed, 4 * l + 0); P.thr16 = c.thr16; P.s0[l] = c.s0; P.s1[l] = c.s1; }
+    P.seedword = seedword;
+    for (int l = 0; l < nlayers; ++l) { const DropCfg c = stream_drop(p, seed, 4 * l + 0, seedword != nullptr, MMT_ATTN_DROP_BITS); P.thr16 = c.thr16; P.s0[l] = c.s0; P.s1[l] = c.s1; }
     return MMT_OK;
 }
 static int launch_mask_gen(uint16_t* mq, uint16_t* mk, const EncDims& D, int nlayers, float p, uint64_t seed, hipStream_t st) {
@@ -343,30 +355,30 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* KR, const bf16* 
     dim3 grid(attn_grid((D.nt + 3) / 4, D.B * D.h));
     const float scale = 1.0f / sqrtf((float)D.L.dk);
     if (drop.thr16 && (!maskQ || !maskK)) return fail(MMT_EINVAL, "attention dropout without mask buffers");
-    if (use_fused_bwd(D)) {                             // one evaluation of P and dS per score: attn_bwd_fused.h
+    if (use_fused_bwd(D)) {                             // one evaluation of P and dS per score, diagonal sweep: attn_bwd_diag.h
         static bool configured = false;
         if (!configured) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_diag16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_diag16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             configured = true;
         }
         ProfScope prof(S_ATTN_BWD_FUSED, st);
-#define MMT_FUSED(dr) hipLaunchKernelGGL((attn_bwd_fused16_kernel<dr>), dim3(D.B * D.h), dim3(MMT_FUSED_THREADS), MMT_FUSED_LDS_BYTES, st, \
-                                          QR, KR, VR, dOR, lse, delta, rowmask, scale, dqkv, D.L.NQ, D.h, D.T, D.nt, maskK, drop.scale)
+#define MMT_DIAG(dr) hipLaunchKernelGGL((attn_bwd_diag16_kernel<dr>), dim3(D.B * D.h), dim3(MMT_DIAG_THREADS), MMT_DIAG_LDS_BYTES, st, \
+                                         QR, KR, VR, dOR, lse, delta, rowmask, scale, dqkv, D.L.NQ, D.h, D.T, D.nt, maskK, drop.scale)
 #ifdef MMT_ABLATIONS
         static const bool stamp = getenv("MMT_ABL") && atoi(getenv("MMT_ABL")) == 7;
         if (stamp && drop.thr16) {
             static bool c2 = false;
-            if (!c2) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); c2 = true; }
-            hipLaunchKernelGGL((attn_bwd_fused16_kernel<true, true>), dim3(D.B * D.h), dim3(MMT_FUSED_THREADS), MMT_FUSED_LDS_BYTES, st,
+            if (!c2) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_diag16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); c2 = true; }
+            hipLaunchKernelGGL((attn_bwd_diag16_kernel<true, true>), dim3(D.B * D.h), dim3(MMT_DIAG_THREADS), MMT_DIAG_LDS_BYTES, st,
                                QR, KR, VR, dOR, lse, delta, rowmask, scale, dqkv, D.L.NQ, D.h, D.T, D.nt, maskK, drop.scale);
-            LAUNCH_CHECK("attn_bwd_fused16_kernel");
+            LAUNCH_CHECK("attn_bwd_diag16_kernel");
             return MMT_OK;
         }
 #endif
-        if (drop.thr16) MMT_FUSED(true); else MMT_FUSED(false);
-#undef MMT_FUSED
-        LAUNCH_CHECK("attn_bwd_fused16_kernel");
+        if (drop.thr16) MMT_DIAG(true); else MMT_DIAG(false);
+#undef MMT_DIAG
+        LAUNCH_CHECK("attn_bwd_diag16_kernel");
         return MMT_OK;
     }
     {
@@ -422,10 +434,11 @@ extern "C" size_t mmt_encoder_workspace_bytes_eval(int B, int T, int d, int h, i
 
 static const float LOG2E = 1.4426950408889634f;
 
-extern "C" int mmt_encoder_forward(const float* x, const float* mask, const float* params, float* y,
-                                   void* workspace, size_t workspace_bytes,
-                                   int B, int T, int d, int h, int f, int n_layers, float eps,
-                                   float dropout_p, uint64_t seed, mmt_stream_t stream) {
+// seed_state != nullptr: device-resident seed (see common.h): the seed is read from, and advanced in, device memory by the first kernel
+static int encoder_forward_impl(const float* x, const float* mask, const float* params, float* y,
+                                void* workspace, size_t workspace_bytes,
+                                int B, int T, int d, int h, int f, int n_layers, float eps,
+                                float dropout_p, uint64_t seed, uint64_t* seed_state, mmt_stream_t stream) {
     EncDims D;
     int rc = make_dims(D, B, T, d, h, f, n_layers);
     if (rc) return rc;
@@ -436,11 +449,18 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const LayerLayout& L = D.L;
+    const bool devseed = seed_state != nullptr && dropout_p > 0.f;
+    const uint64_t* seedword = devseed ? W.seedword : nullptr;
+    if (devseed) {
+        hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, st, seed_state, W.seedword);
+        LAUNCH_CHECK("seed_advance_kernel");
+    }
+    auto mkdrop = [&](int stream_id) { return stream_drop(dropout_p, seed, (uint32_t)stream_id, devseed, (stream_id & 3) == 0 ? MMT_ATTN_DROP_BITS : 16); };
 
     if (D.N > 0 && dropout_p > 0.f) {
         // weight preparation + every attention-dropout decision of this forward pass (and of its backward), all layers: one launch
         MaskGenParams P;
-        if ((rc = fill_mask_gen(P, W.lw[0].maskQ, W.lw[0].maskK, D, D.N, dropout_p, seed))) return rc;
+        if ((rc = fill_mask_gen(P, W.lw[0].maskQ, W.lw[0].maskK, D, D.N, dropout_p, seed, seedword))) return rc;
         const size_t blocks = (size_t)P.nbh * P.nt * P.nt;
         const int gen_blocks = (int)((blocks + 255) / 256), prep_blocks = std::min(grid_for(L.pstride() + L.qstride()), 64);
         ProfScope prof(S_MASK_GEN, st);
@@ -480,7 +500,7 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
             if ((rc = launch_rowgemm<EPI_FRAG, true>(p, st, S_LN1_QKV))) return rc;
         }
         // dropout streams of layer l: 4l+0 attention probabilities (:33), 4l+1 / 4l+3 sublayer outputs (:104), 4l+2 FFN hidden (:20)
-        if ((rc = launch_attn_fwd(L.DKP, w.QR, w.KR, w.VR, w.ctx, w.lse, D, st, make_drop(dropout_p, seed, 4 * l + 0), w.maskQ))) return rc;
+        if ((rc = launch_attn_fwd(L.DKP, w.QR, w.KR, w.VR, w.ctx, w.lse, D, st, mkdrop(4 * l + 0), w.maskQ))) return rc;
         {   // out-proj + residual -> LN2 + FFN1 + ReLU -> FFN2 + residual, one kernel, x1 and hid stay in LDS
             RowChain3 ch; memset(&ch, 0, sizeof(ch));
             {   RowGemmParams& p = ch.a; p = rg_zero();
@@ -488,19 +508,19 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
                 p.A = w.ctx; p.a_bf16 = 1; p.lda = L.HDP;
                 p.W = wp + L.pWo(); p.bias = bp + L.qbo();
                 p.residual = xin; p.ldr = d; p.out_f32 = w.x1; p.ldo = d;
-                p.drop = make_drop(dropout_p, seed, 4 * l + 1); }
+                p.drop = mkdrop(4 * l + 1); p.seedword = seedword; }
             {   RowGemmParams& p = ch.b; p = rg_zero();
                 p.M = D.M; p.K = d; p.KP = L.DP; p.N = f; p.NP = L.FP;
                 p.A_out = w.xn2; p.lda_out = L.DP;
                 p.ln_a = P + L.oln(2); p.ln_b = P + L.oln(3); p.eps = eps; p.stats = w.stats2;
                 p.W = wp + L.pW1(); p.bias = bp + L.qb1(); p.act = 1;
                 p.out_bf16 = w.hid; p.ldo16 = L.FP; p.n_store16 = L.FP;
-                p.drop = make_drop(dropout_p, seed, 4 * l + 2); }
+                p.drop = mkdrop(4 * l + 2); p.seedword = seedword; }
             {   RowGemmParams& p = ch.c; p = rg_zero();
                 p.M = D.M; p.K = L.FP; p.KP = L.FP; p.N = d; p.NP = L.DP;
                 p.W = wp + L.pW2(); p.bias = bp + L.qb2();
                 p.out_f32 = w.xout; p.ldo = d;
-                p.drop = make_drop(dropout_p, seed, 4 * l + 3); }
+                p.drop = mkdrop(4 * l + 3); p.seedword = seedword; }
             ch.ldx = L.DP + 4; ch.lda2 = L.FP + 8;
             if (l + 1 < D.N && fuse_next_qkv) {
                 RowChain4 c4; memset(&c4, 0, sizeof(c4));
@@ -530,6 +550,20 @@ extern "C" int mmt_encoder_forward(const float* x, const float* mask, const floa
     return MMT_OK;
 }
 
+extern "C" int mmt_encoder_forward(const float* x, const float* mask, const float* params, float* y,
+                                   void* workspace, size_t workspace_bytes,
+                                   int B, int T, int d, int h, int f, int n_layers, float eps,
+                                   float dropout_p, uint64_t seed, mmt_stream_t stream) {
+    return encoder_forward_impl(x, mask, params, y, workspace, workspace_bytes, B, T, d, h, f, n_layers, eps, dropout_p, seed, nullptr, stream);
+}
+extern "C" int mmt_encoder_forward_devseed(const float* x, const float* mask, const float* params, float* y,
+                                           void* workspace, size_t workspace_bytes,
+                                           int B, int T, int d, int h, int f, int n_layers, float eps,
+                                           float dropout_p, uint64_t* seed_state, mmt_stream_t stream) {
+    if (!seed_state) return fail(MMT_EINVAL, "null seed state");
+    return encoder_forward_impl(x, mask, params, y, workspace, workspace_bytes, B, T, d, h, f, n_layers, eps, dropout_p, 0, seed_state, stream);
+}
+
 static int launch_ln_bwd(const float* dy, const float* x, const float* a, const float* stats, float eps, float* dx,
                          float* colpart, int M, int d, int DP, hipStream_t st) {
     const size_t lds = (size_t)2 * 32 * (DP + 4) * 4;
@@ -546,11 +580,12 @@ static int launch_ln_bwd(const float* dy, const float* x, const float* a, const 
     return MMT_OK;
 }
 
-extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float* mask, const float* params,
-                                    float* dx, float* dparams,
-                                    void* workspace, size_t workspace_bytes,
-                                    int B, int T, int d, int h, int f, int n_layers, float eps,
-                                    float dropout_p, uint64_t seed, mmt_stream_t stream) {
+// devseed: the forward was device-seeded; its seed sits in the workspace's seed word
+static int encoder_backward_impl(const float* dy, const float* x, const float* mask, const float* params,
+                                 float* dx, float* dparams,
+                                 void* workspace, size_t workspace_bytes,
+                                 int B, int T, int d, int h, int f, int n_layers, float eps,
+                                 float dropout_p, uint64_t seed, bool devseed_in, mmt_stream_t stream) {
     EncDims D;
     int rc = make_dims(D, B, T, d, h, f, n_layers);
     if (rc) return rc;
@@ -560,6 +595,9 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const LayerLayout& L = D.L;
+    const bool devseed = devseed_in && dropout_p > 0.f;
+    const uint64_t* seedword = devseed ? W.seedword : nullptr;
+    auto mkdrop = [&](int stream_id) { return stream_drop(dropout_p, seed, (uint32_t)stream_id, devseed, (stream_id & 3) == 0 ? MMT_ATTN_DROP_BITS : 16); };
 
     // final LayerNorm
     const float* Pf = params + (size_t)D.N * L.stride();
@@ -592,7 +630,7 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             p.W = wp + L.pW2T();
             p.relu_mask = w.hid; p.ldm = L.FP;          // hid > 0  <=>  ReLU passed AND the unit was kept
             p.mask_scale = make_drop(dropout_p, seed, 4 * l + 2).scale;
-            p.a_drop = make_drop(dropout_p, seed, 4 * l + 3);   // gradient of the dropped sublayer-1 output
+            p.a_drop = mkdrop(4 * l + 3); p.seedword = seedword;   // gradient of the dropped sublayer-1 output
             p.out_bf16 = w.dh; p.ldo16 = L.FP; p.n_store16 = L.FP; }
         {   RowGemmParams& p = ch.b; p = rg_zero();           // dx1 = dx2 + LN2bwd(dh W1)
             p.M = D.M; p.K = L.FP; p.KP = L.FP; p.N = d; p.NP = L.DP;
@@ -600,7 +638,7 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             p.x = w.x1; p.ldx = d; p.st = w.stats2; p.ln_a = P + L.oln(2); p.eps = eps; p.d_real = d;
             p.dres = cur; p.lddres = d; p.out_f32 = other; p.ldo = d; p.colpart = w.lnpart2;
             p.no_gs = L.DP > 128;                               // d_model > 128: a second fp32 tile would leave one workgroup per CU
-            p.next_drop = make_drop(dropout_p, seed, 4 * l + 1);   // gradient of the dropped sublayer-0 output, applied to the next A tile
+            p.next_drop = mkdrop(4 * l + 1); p.seedword = seedword;   // gradient of the dropped sublayer-0 output, applied to the next A tile
             p.next_lda = L.DP + 8; }
         {   RowGemmParams& p = ch.c; p = rg_zero();           // dO = drop'(dx1) Wo -> fragments + delta   [emits dx1 as bf16 rows]
             p.M = D.M; p.K = d; p.KP = L.DP; p.N = L.HD; p.NP = L.HDP;
@@ -639,13 +677,14 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
             if (rc) return rc;
         }
         if ((rc = launch_attn_bwd(L.DKP, w.QR, w.KR, w.VR, W.dOR, w.lse, W.delta, mask,
-                                  w.dqkv, D, st, make_drop(dropout_p, seed, 4 * l + 0), w.maskQ, w.maskK))) return rc;
+                                  w.dqkv, D, st, mkdrop(4 * l + 0), w.maskQ, w.maskK))) return rc;
         float* dxin = (l > 0) ? cur : dx;
         if (l > 0 && boundary) {
             RowChain3 below; build_chain(l - 1, below);        // (its stages read `cur` = the dx this kernel's first stage writes)
             RowChain4 c4; memset(&c4, 0, sizeof(c4));
             c4.a = build_qkv(l, dxin);
             c4.a.next_drop = below.a.a_drop; c4.a.next_lda = below.a.KP + 8;      // next A tile = bf16(drop'(dx)), left in LDS
+            c4.a.seedword = seedword;
             c4.b = below.a; c4.c = below.b; c4.d = below.c; c4.ldx = 0; c4.lda2 = below.lda2;
             if (c4.a.no_gs != c4.c.no_gs) { c4.a.no_gs = c4.c.no_gs = 1; }        // (one WIDE flag per kernel: K-chunking alone implies it)
             if (c4.a.no_gs) rc = launch_rowchain(encoder_bwd_boundary_kernel<true>, c4, true, S_BWD_BOUNDARY, "encoder_bwd_boundary_kernel", st, L.DP);
@@ -698,6 +737,21 @@ extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float
         LAUNCH_CHECK("ln_param_finalize_kernel");
     }
     return MMT_OK;
+}
+
+extern "C" int mmt_encoder_backward(const float* dy, const float* x, const float* mask, const float* params,
+                                    float* dx, float* dparams,
+                                    void* workspace, size_t workspace_bytes,
+                                    int B, int T, int d, int h, int f, int n_layers, float eps,
+                                    float dropout_p, uint64_t seed, mmt_stream_t stream) {
+    return encoder_backward_impl(dy, x, mask, params, dx, dparams, workspace, workspace_bytes, B, T, d, h, f, n_layers, eps, dropout_p, seed, false, stream);
+}
+extern "C" int mmt_encoder_backward_devseed(const float* dy, const float* x, const float* mask, const float* params,
+                                            float* dx, float* dparams,
+                                            void* workspace, size_t workspace_bytes,
+                                            int B, int T, int d, int h, int f, int n_layers, float eps,
+                                            float dropout_p, mmt_stream_t stream) {
+    return encoder_backward_impl(dy, x, mask, params, dx, dparams, workspace, workspace_bytes, B, T, d, h, f, n_layers, eps, dropout_p, 0, true, stream);
 }
 
 // ------------------------------------------------------------------------------------ LayerNorm alone
@@ -815,7 +869,7 @@ extern "C" int mmt_sdpa_forward(const float* q, const float* k, const float* v, 
     hipLaunchKernelGGL(pack_frag_kernel, dim3(g), dim3(256), 0, st, v, W.VR, nullptr, 1.f, 0, nullptr, 0, nullptr, D.M, T, D.Tp, h, L.dk, L.DKP, d);
     LAUNCH_CHECK("pack_frag_kernel");
     if (dropout_p > 0.f && (rc = launch_mask_gen(W.maskQ, W.maskK, D, 1, dropout_p, seed, st))) return rc;
-    if ((rc = launch_attn_fwd(L.DKP, W.QR, W.KR, W.VR, W.ctx, W.lse, D, st, make_drop(dropout_p, seed, 0), W.maskQ))) return rc;
+    if ((rc = launch_attn_fwd(L.DKP, W.QR, W.KR, W.VR, W.ctx, W.lse, D, st, make_drop(dropout_p, seed, 0, MMT_ATTN_DROP_BITS), W.maskQ))) return rc;
     hipLaunchKernelGGL(unpad_heads_kernel, dim3(grid_for((size_t)D.M * d)), dim3(256), 0, st, W.ctx, L.HDP, 0, ctx, D.M, h, L.dk, L.DKP, d);
     LAUNCH_CHECK("unpad_heads_kernel");
     return MMT_OK;
@@ -837,7 +891,7 @@ extern "C" int mmt_sdpa_backward(const float* dctx, const float* mask, float* dq
                        W.ctx, L.HDP, W.delta, D.M, T, D.Tp, h, L.dk, L.DKP, d);
     LAUNCH_CHECK("pack_frag_kernel");
     if ((rc = launch_attn_bwd(L.DKP, W.QR, W.KR, W.VR, W.dOR, W.lse, W.delta, mask, W.dqkv, D, st,
-                              make_drop(dropout_p, seed, 0), W.maskQ, W.maskK))) return rc;     // the masks the forward generated
+                              make_drop(dropout_p, seed, 0, MMT_ATTN_DROP_BITS), W.maskQ, W.maskK))) return rc;     // the masks the forward generated
     const int g = grid_for((size_t)D.M * d);
     hipLaunchKernelGGL(unpad_heads_kernel, dim3(g), dim3(256), 0, st, W.dqkv, L.NQ, 0, dq, D.M, h, L.dk, L.DKP, d);
     hipLaunchKernelGGL(unpad_heads_kernel, dim3(g), dim3(256), 0, st, W.dqkv, L.NQ, L.HD, dk, D.M, h, L.dk, L.DKP, d);
@@ -1201,9 +1255,10 @@ extern "C" int mmt_convpool_backward(const float* x, const float* dout, const in
 }
 
 // ------------------------------------------------------------------------------------ MFN memory scan
-struct MfnWs { bf16 *WmF, *W2F, *WmB, *W2B; size_t bytes; };
+struct MfnWs { uint64_t* seedword; bf16 *WmF, *W2F, *WmB, *W2B; size_t bytes; };
 static void carve_mfn(MfnWs& W, void* base) {
     Carver c(base);
+    W.seedword = c.take<uint64_t>(1);
     W.WmF = c.take<bf16>(MFN_U * MFN_MD); W.W2F = c.take<bf16>(2 * MFN_MD * MFN_HG);
     W.WmB = c.take<bf16>(MFN_MD * MFN_U); W.W2B = c.take<bf16>(MFN_U * MFN_MD);
     W.bytes = c.off;
@@ -1216,9 +1271,9 @@ static int check_mfn_dims(int mem_dim, int h_gamma) {
     return MMT_OK;
 }
 
-extern "C" int mmt_mfn_mem_scan_forward(const float* apre, const float* chat, const float* Wm, const float* W2, const float* b2,
-                                        float* mem_all, float* u_all, float* g_all, void* workspace, size_t workspace_bytes,
-                                        int T, int B, int mem_dim, int h_gamma, float dropout_p, uint64_t seed, mmt_stream_t stream) {
+static int mfn_mem_scan_forward_impl(const float* apre, const float* chat, const float* Wm, const float* W2, const float* b2,
+                                     float* mem_all, float* u_all, float* g_all, void* workspace, size_t workspace_bytes,
+                                     int T, int B, int mem_dim, int h_gamma, float dropout_p, uint64_t seed, uint64_t* seed_state, mmt_stream_t stream) {
     int rc = check_mfn_dims(mem_dim, h_gamma);
     if (rc) return rc;
     if (!apre || !chat || !Wm || !W2 || !b2 || !mem_all || !u_all || !g_all || !workspace) return fail(MMT_EINVAL, "null pointer argument");
@@ -1228,11 +1283,27 @@ extern "C" int mmt_mfn_mem_scan_forward(const float* apre, const float* chat, co
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(mfn_prep_kernel, dim3(64), dim3(256), 0, st, Wm, W2, W.WmF, W.W2F, W.WmB, W.W2B);
     LAUNCH_CHECK("mfn_prep_kernel");
+    const bool devseed = seed_state != nullptr && dropout_p > 0.f;
+    if (devseed) {      // the gamma mask is not regenerated by the backward (u_all keeps the dropped values): no copy of the seed is needed after this launch
+        hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, st, seed_state, W.seedword);
+        LAUNCH_CHECK("seed_advance_kernel");
+    }
     ProfScope prof(S_MEM_FWD, st);
     hipLaunchKernelGGL(mfn_mem_scan_fwd_kernel, dim3((B + scan_bt(B) - 1) / scan_bt(B)), dim3(512), 0, st, apre, chat, W.WmF, W.W2F, b2, mem_all, u_all, g_all, T, B, scan_bt(B),
-                       make_drop(dropout_p, seed, 1000));
+                       stream_drop(dropout_p, seed, 1000, devseed), devseed ? W.seedword : nullptr);
     LAUNCH_CHECK("mfn_mem_scan_fwd_kernel");
     return MMT_OK;
+}
+extern "C" int mmt_mfn_mem_scan_forward(const float* apre, const float* chat, const float* Wm, const float* W2, const float* b2,
+                                        float* mem_all, float* u_all, float* g_all, void* workspace, size_t workspace_bytes,
+                                        int T, int B, int mem_dim, int h_gamma, float dropout_p, uint64_t seed, mmt_stream_t stream) {
+    return mfn_mem_scan_forward_impl(apre, chat, Wm, W2, b2, mem_all, u_all, g_all, workspace, workspace_bytes, T, B, mem_dim, h_gamma, dropout_p, seed, nullptr, stream);
+}
+extern "C" int mmt_mfn_mem_scan_forward_devseed(const float* apre, const float* chat, const float* Wm, const float* W2, const float* b2,
+                                                float* mem_all, float* u_all, float* g_all, void* workspace, size_t workspace_bytes,
+                                                int T, int B, int mem_dim, int h_gamma, float dropout_p, uint64_t* seed_state, mmt_stream_t stream) {
+    if (!seed_state) return fail(MMT_EINVAL, "null seed state");
+    return mfn_mem_scan_forward_impl(apre, chat, Wm, W2, b2, mem_all, u_all, g_all, workspace, workspace_bytes, T, B, mem_dim, h_gamma, dropout_p, 0, seed_state, stream);
 }
 
 extern "C" int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* chat, const float* mem_all, const float* u_all,
@@ -1357,7 +1428,7 @@ extern "C" int mmt_debug_poison_lds(uint32_t pattern, void* sink4, mmt_stream_t 
 extern "C" int mmt_debug_dropout_mask(float p, uint64_t seed, uint32_t stream_id, uint64_t n, uint32_t attn_Tp, uint8_t* keep,
                                       float* scale_out, mmt_stream_t stream) {
     if (!keep) return fail(MMT_EINVAL, "null pointer argument");
-    const DropCfg c = make_drop(p, seed, stream_id);
+    const DropCfg c = make_drop(p, seed, stream_id, attn_Tp ? MMT_ATTN_DROP_BITS : 16);
     if (scale_out) *scale_out = c.scale;        // host pointer
     if (attn_Tp) {                              // attention-probability stream: the generator's own block function (attn_mask.h)
         if (attn_Tp % 32 || n % ((uint64_t)attn_Tp * attn_Tp)) return fail(MMT_EINVAL, "attention mask: n must be a multiple of Tp*Tp, Tp of 32");

@@ -1,0 +1,303 @@
+// Attention backward in ONE kernel for d_k <= 16 and 9..16 key tiles (T = 257..512: configs[1], configs[3]): dQ, dK and dV from a
+// single evaluation of P = 2^(S'-L) and dS = P (dP - delta) per score.  Both two-kernel forms (attn.h) are VALU-issue bound (exp, the
+// dropout selects, the bf16 converts), so evaluating every score once instead of twice is what the fusion buys; the MFMA work is unchanged.
+//
+// One workgroup of 16 waves owns one (batch, head); EVERYTHING it needs is resident in LDS for the whole launch (151 KB of the CU's 160):
+//   * all query tiles of the head: Q', dO (R fragment layout, 8-feature groups 576 bytes apart for the transposing reads), L and delta
+//     (16 x 2.5 KB).  Round 2 streamed them through a three-deep ring, one tile per step for all waves: a global fetch, an LDS store
+//     and a wait per thread and step, and every wave had to be on the SAME query tile;
+//   * each wave's own key tile (K and V) and its private dS patch;
+//   * one fp32 dQ^T accumulator tile per query tile (16 x 2.1 KB).
+// Wave w owns key tile w and keeps dK^T / dV^T of that tile in ONE accumulator (rows 0..15 dV^T, rows 16..31 dK^T: the d_k = 16 trick
+// of attn_bwd_dkv_kernel).  The sweep over the query tiles is DIAGONAL: at step t wave w works on query tile (w + t) mod nt, so the
+// 16 waves are on 16 different query tiles and each dQ accumulator is touched by exactly one wave per step.  The wave adds its 32-key
+// share of dQ^T = K^T dS^T to that accumulator with a plain read-add-write — no atomics, and the order in which the shares of a
+// query tile are added (waves q, q-1, q-2, ... mod nt) is fixed, so the result is bit-reproducible.  Round 2 had all 16 waves write
+// fp32 partials of the SAME query tile, meet at a barrier, sum the 16 partials and store, every step (13 % of the tile time plus
+// most of the barrier's 24 %).  One barrier per step remains (it orders step t's accumulator writes before step t+1's reads by the
+// neighbouring wave) but nothing else synchronises: no staging, no reduction, no global traffic inside the sweep except the lane's
+// 16-bit dropout word.  dQ leaves LDS once, at the end (scale 1/sqrt(d_k), query-row mask, bf16, 32 contiguous bytes per query).
+//   * dS sits in the accumulator layout with the key on the lane; the dQ product contracts over keys, so dS goes through the wave's
+//     LDS patch to become a B operand: two 16-byte stores per lane of the packed values as they lie, read back transposed;
+//   * the products that contract over windows (dV^T += dO^T P, dK^T += Q'^T dS over the queries, dQ^T = K^T dS^T over the keys) take
+//     their A fragments out of the resident tiles with transposing LDS reads (common.h tr_frag2);
+//   * the score products S, dP of the wave's NEXT query tile are issued before the step's barrier, so a wave leaves the barrier with
+//     VALU work on finished MFMA results;
+//   * queries >= T (last tile): their L is staged as -inf, so P = 2^(S' - inf) = 0 exactly and no tile needs a special body.
+// Registers: 16 waves per CU means 128 VGPRs per wave.
+//
+// Reference semantics: transformer/MFT/multiTransformer.py:22-34 (scaled dot-product attention) under autograd.
+#pragma once
+#include "attn.h"
+
+#define MMT_DIAG_NW 16
+#define MMT_DIAG_THREADS (MMT_DIAG_NW * 64)
+#define MMT_DIAG_PATCH_LD 40                                // bf16 per patch row (one key): 2 halves x 16 accumulator slots + 8 pad (80-byte rows: conflict-free b128 writes)
+#define MMT_DIAG_PART_LD 68                                 // floats per dQ accumulator register row: 64 lanes + 4 pad
+#define MMT_DIAG_PATCH_BYTES (32 * MMT_DIAG_PATCH_LD * 2)   // 2560
+#define MMT_DIAG_ACC_BYTES (8 * MMT_DIAG_PART_LD * 4)       // 2176: feature rows < 16 of a 32x32 accumulator = 8 registers
+#define MMT_DIAG_RT_PIECES (2 * MMT_TR_OCT)                 // an R tile of d_k = 16 in LDS: two 8-feature groups, 576 bytes apart (attn.h TileStager)
+#define MMT_DIAG_QD_PIECES (2 * MMT_DIAG_RT_PIECES + 16)    // LDS pieces per query tile: Q, dO, 2 * 8 pieces of row constants
+#define MMT_DIAG_QD_LOADS 144                               // 16-byte pieces fetched per query tile: 2 * 64 + 2 * 8
+#define MMT_DIAG_ZERO_BYTES 512
+#define MMT_DIAG_LDS_BYTES (MMT_DIAG_NW * MMT_DIAG_QD_PIECES * 16 + MMT_DIAG_ZERO_BYTES + MMT_DIAG_NW * 2 * MMT_DIAG_RT_PIECES * 16 \
+                            + MMT_DIAG_NW * MMT_DIAG_PATCH_BYTES + MMT_DIAG_NW * MMT_DIAG_ACC_BYTES)      // 154,112 of 163,840
+
+__host__ inline bool attn_bwd_fused_ok(int DKP, int nt) { return DKP == 16 && nt > 8 && nt <= MMT_DIAG_NW; }
+
+// STAMP (diagnostic build, -DMMT_ABLATIONS): s_memtime at six points of the step body, summed per wave into g_attn_stamps
+#ifdef MMT_ABLATIONS
+#define FB_STAMP(n) do { if (STAMP) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    st_acc[n] += t_ - st_prev; st_prev = t_; } } while (0)
+#else
+#define FB_STAMP(n)
+#endif
+template <bool DROP, bool STAMP = false>
+__global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
+        const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vr, const bf16* __restrict__ dOr,
+        const float* __restrict__ lse, const float* __restrict__ delta, const float* __restrict__ rowmask, float scale,
+        bf16* __restrict__ dqkv, int lddkv,     // row-major [M][lddkv]: dQ at column 0, dK at HD, dV at 2*HD
+        int h, int T, int nt, const uint16_t* __restrict__ maskK, float drop_scale) {
+    constexpr int DKP = 16, RT = MMT_DIAG_RT_PIECES, TOTAL = MMT_DIAG_QD_PIECES, NW = MMT_DIAG_NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* const qd0 = reinterpret_cast<bf16*>(smem);                                    // [NW][TOTAL * 8] bf16: every query tile of the head
+    const bf16* const zeros = reinterpret_cast<const bf16*>(smem + NW * TOTAL * 16);    // what the padding feature rows of an A fragment read
+    char* const kvl0 = smem + NW * TOTAL * 16 + MMT_DIAG_ZERO_BYTES;                    // [NW][2][RT * 16]: own K and V tiles (R layout, padded groups)
+    char* const patch0 = kvl0 + NW * 2 * RT * 16;                                       // [NW][PATCH_BYTES]: wave-private dS patches
+    float* const dqacc0 = reinterpret_cast<float*>(patch0 + NW * MMT_DIAG_PATCH_BYTES); // [NW query tiles][8][PART_LD] fp32
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int kt = wave;
+    const bool live = kt < nt;                          // idle waves take part in the staging, the barriers and nothing else
+    const int bh = blockIdx.x, b = bh / h, head = bh - b * h;
+    const int Tp = nt * 32, HD = h * DKP;
+    const size_t offR = (size_t)bh * fragR_elems(Tp, DKP);
+    // dropout: this lane's words of the wave's row of mask blocks (attn_mask.h, LK layout: key on the lane), one per query tile, a step ahead
+    const uint16_t* mrow = maskK + ((size_t)bh * nt + (live ? kt : 0)) * nt * 64 + lane;
+    int qt = live ? kt : 0;                             // the wave's query tile of step t: (kt + t) mod nt
+    uint32_t mw = DROP ? mrow[(size_t)qt * 64] : 0u;
+    const uint32_t scale_bits = __builtin_bit_cast(uint32_t, drop_scale);
+
+    // ---- prologue: every query tile of the head -> LDS (thread p moves pieces p, p + 1024, p + 2048 of the nt * 144), own K / V tile
+    {
+        const bf16* const lsrc = reinterpret_cast<const bf16*>(lse + (size_t)bh * Tp);
+        const bf16* const dsrc = reinterpret_cast<const bf16*>(delta + (size_t)bh * Tp);
+        const int npieces = nt * MMT_DIAG_QD_LOADS;
+        bf16x8 reg[3]; int dst[3]; int lrow[3];          // lrow: first query of an L piece (-1: not one)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int p = tid + i * MMT_DIAG_THREADS;
+            dst[i] = -1; lrow[i] = -1;
+            if (p < npieces) {
+                const int tile = p / MMT_DIAG_QD_LOADS, q = p - tile * MMT_DIAG_QD_LOADS;
+                const bf16* src; int d;
+                if (q < 64) { src = Qr + offR + (size_t)tile * 32 * DKP + q * 8; d = q + (q >> 5) * (MMT_TR_OCT - 32); }
+                else if (q < 128) { src = dOr + offR + (size_t)tile * 32 * DKP + (q - 64) * 8; d = RT + (q - 64) + ((q - 64) >> 5) * (MMT_TR_OCT - 32); }
+                else if (q < 136) { src = lsrc + (size_t)tile * 64 + (q - 128) * 8; d = 2 * RT + (q - 128); lrow[i] = tile * 32 + (q - 128) * 4; }
+                else { src = dsrc + (size_t)tile * 64 + (q - 136) * 8; d = 2 * RT + 8 + (q - 136); }
+                reg[i] = *reinterpret_cast<const bf16x8*>(src);
+                dst[i] = (tile * TOTAL + d) * 8;
+            }
+        }
+        if (tid < MMT_DIAG_ZERO_BYTES / 4) reinterpret_cast<unsigned*>(smem + NW * TOTAL * 16)[tid] = 0u;
+        {
+            const int ktc = live ? kt : 0;
+            const size_t off = ((size_t)(ktc * (DKP / 8) + hh) * 32 + r) * 8;
+            char* const mykv = kvl0 + wave * (2 * RT * 16) + (hh * MMT_TR_OCT + r) * 16;
+            *reinterpret_cast<bf16x8*>(mykv) = *reinterpret_cast<const bf16x8*>(Kr + offR + off);
+            *reinterpret_cast<bf16x8*>(mykv + RT * 16) = *reinterpret_cast<const bf16x8*>(Vr + offR + off);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (dst[i] < 0) continue;
+            if (lrow[i] >= 0) {                          // -L of queries >= T: -inf, so that P = 2^(S' - L) = 0 exactly for them
+                f32x4 v = __builtin_bit_cast(f32x4, reg[i]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (lrow[i] + e < T) ? v[e] : -INFINITY;
+                reg[i] = __builtin_bit_cast(bf16x8, v);
+            }
+            *reinterpret_cast<bf16x8*>(qd0 + dst[i]) = reg[i];
+        }
+    }
+
+    f32x16 acc;                                         // rows 0..15: dV^T, rows 16..31: dK^T (see attn_bwd_dkv_kernel)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    const bool key_tail = live && (kt == nt - 1) && (T & 31);
+    const uint32_t kcol = (uint32_t)(kt * 32 + r);
+    const uint32_t m0 = (uint32_t)b * (uint32_t)T;
+    __syncthreads();
+
+    f32x16 s, dp;                       // S' - L and dP (- delta) of the current tile, produced one step ahead
+    // LDS addresses derived from the lane id are recomputed where they are used, from an opaque copy of it: kept as loop invariants
+    // they are what spills at 128 VGPRs.
+    auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
+    auto scores = [&](int tile) {       // row constants (4 consecutive queries per register group) are the accumulator init
+        const int lo = opaque(lane), r = lo & 31, hh = lo >> 5;
+        char* const mykv = kvl0 + wave * (2 * RT * 16) + (hh * MMT_TR_OCT + r) * 16;
+        const bf16* sq = qd0 + (size_t)tile * TOTAL * 8;
+        const bf16* sdo = sq + RT * 8;
+        const float* sl = reinterpret_cast<const float*>(sq + 2 * RT * 8);
+        const float* sd = sl + 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(sl + 8 * g + 4 * hh);
+            f32x4 d4 = {0.f, 0.f, 0.f, 0.f};                                   // DROP: -delta enters after the mask
+            if (!DROP) d4 = *reinterpret_cast<const f32x4*>(sd + 8 * g + 4 * hh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s[4 * g + i] = l4[i]; dp[4 * g + i] = d4[i]; }      // both stored negated
+        }
+        const int o8 = (hh * MMT_TR_OCT + r) * 8;
+        s = mfma32(*reinterpret_cast<const bf16x8*>(sq + o8), *reinterpret_cast<const bf16x8*>(mykv), s);
+        dp = mfma32(*reinterpret_cast<const bf16x8*>(sdo + o8), *reinterpret_cast<const bf16x8*>(mykv + RT * 16), dp);
+    };
+    if (live) scores(qt);
+    else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s[j] = 0.f; dp[j] = 0.f; }
+    }
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0, st_entry = 0;
+    (void)st_acc; (void)st_prev; (void)st_entry;
+#ifdef MMT_ABLATIONS
+    if (STAMP) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory"); st_entry = st_prev; }
+#endif
+
+    auto body = [&](auto first_tag, auto next_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;                      // step 0: the dQ accumulators are written, not added to
+        constexpr bool NEXT = decltype(next_tag)::value;                        // a step t + 1 exists
+        const int qn = (qt + 1 == nt) ? 0 : qt + 1;
+        f32x16 dqp;
+        FB_STAMP(0);                                    // loop top
+        if (live) {
+            const uint32_t tw = mw;
+            if (DROP && NEXT) mw = mrow[(size_t)qn * 64];
+            const bf16* const sqc = qd0 + (size_t)qt * TOTAL * 8;               // this tile's Q (then dO, L, delta)
+            const float* sd = reinterpret_cast<const float*>(sqc + 2 * RT * 8) + 32;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s[j] = fast_exp2(s[j]);                // queries >= T: exactly 0 (their L was staged as -inf)
+            if (key_tail) {                             // wave-uniform, loop-invariant: only the last key tile's wave pays
+                const float kmul = ((int)kcol < T) ? 1.f : 0.f;        // keys >= T do not exist
+#pragma unroll
+                for (int j = 0; j < 16; ++j) s[j] *= kmul;
+            }
+            if (DROP) {
+                static_for<0, 4>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(sd + 8 * g + 4 * hh);
+                    static_for<0, 4>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value, j = 4 * g + i;
+                        const float ms = __builtin_bit_cast(float, scale_bits & keep_bits<j>(tw));     // 1/(1-p) where (query of register j, this lane's key) was kept
+                        dp[j] = s[j] * fmaf(dp[j], ms, d4[i]);
+                        s[j] *= ms;
+                    });
+                });
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) dp[j] *= s[j];
+            }
+            FB_STAMP(1);                                // exponentials, dropout, dS
+            // dV^T / dK^T, and dS into the patch on the way.  A fragments by transposing reads of the resident dO / Q tiles: the lane
+            // SUPPLIES the address of query tq of a 4-query block, features 4 tpp .. + 3, and receives feature (lane & 15); fragment slot j
+            // <-> query 16 s2 + 8 (j >> 2) + 4 hh + (j & 3), the row order of the P / dS accumulators.  dV^T lives in accumulator rows
+            // 0..15 (lanes r < 16 read dO, the others zeros), dK^T in rows 16..31 (lanes r >= 16 read Q, the others zeros).
+            const int lo = opaque(lane), r = lo & 31, hh = lo >> 5;
+            const int tq = (lo >> 2) & 3, tpp = lo & 3, toff = (tpp >> 1) * (MMT_TR_OCT * 8) + 4 * (tpp & 1) + tq * 8;
+            const bool up = (lo >> 4) & 1;
+            const bf16* const ado = up ? zeros : sqc + RT * 8 + toff + 32 * hh;
+            const bf16* const aq = up ? sqc + toff + 32 * hh : zeros;
+            bf16* const patch = reinterpret_cast<bf16*>(patch0 + wave * MMT_DIAG_PATCH_BYTES);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pds = pack8(dp, s2);
+                acc = mfma32(tr_frag2(ado + 128 * s2, ado + 128 * s2 + 64), pack8(s, s2), acc);
+                acc = mfma32(tr_frag2(aq + 128 * s2, aq + 128 * s2 + 64), pds, acc);
+                // patch row = this lane's key; slots [hh][8 s2 + j] = query acc32_row(8 s2 + j, hh): every aligned group of 4 slots
+                // is 4 consecutive queries, the unit a transposing read hands out
+                *reinterpret_cast<bf16x8*>(patch + r * MMT_DIAG_PATCH_LD + 16 * hh + 8 * s2) = pds;
+            }
+            FB_STAMP(2);                                // packs, dV/dK products, patch writes
+            // dQ^T share of this key tile: K^T (features x keys) times dS^T (keys x queries).  K^T fragments by transposing reads of
+            // the own K tile: slot j <-> key 16 s2 + 8 hh + j, the patch's column order; lanes r >= 16 would produce the padding
+            // feature rows, which nobody reads: they supply (and receive) the same as lanes r - 16
+            const bf16* const ak = reinterpret_cast<const bf16*>(kvl0 + wave * (2 * RT * 16)) + toff + 64 * hh;
+            // dS^T fragments: this lane supplies key tq of a 4-key block and the 4 queries 16 up + 4 tpp .. + 3 (patch slots
+            // [tpp & 1][4 (2 up + (tpp >> 1)) ..]) and receives its own query r for those keys; slot j <-> key 16 s2 + 8 hh + j
+            const bf16* const pb = patch + (8 * hh + tq) * MMT_DIAG_PATCH_LD + 16 * (tpp & 1) + 4 * (2 * (int)up + (tpp >> 1));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dqp[j] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 bfrag = tr_frag2(pb + 16 * MMT_DIAG_PATCH_LD * s2, pb + 16 * MMT_DIAG_PATCH_LD * s2 + 4 * MMT_DIAG_PATCH_LD);
+                dqp = mfma32(tr_frag2(ak + 128 * s2, ak + 128 * s2 + 32), bfrag, dqp);
+            }
+            FB_STAMP(3);                                // patch reads, dQ product
+            if (NEXT) scores(qn);                       // the next query tile of this wave: resident, no dependence on the barrier
+            FB_STAMP(4);                                // next tile's row constants, operand reads and score products
+        }
+        // step t - 1's additions to the accumulator of query tile qt (by the wave that owns key tile kt + 1) are complete and visible
+        // behind this barrier; this wave's own additions of step t are ordered before the next step's barrier by its lgkmcnt(0)
+        if (!FIRST) lds_barrier();
+        FB_STAMP(5);                                    // barrier
+        if (live) {
+            float* const slot = dqacc0 + (size_t)qt * (MMT_DIAG_ACC_BYTES / 4) + opaque(lane);
+            if (FIRST) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) slot[j * MMT_DIAG_PART_LD] = dqp[j];          // feature rows >= 16 are padding
+            } else {
+                float old[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) old[j] = slot[j * MMT_DIAG_PART_LD];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) slot[j * MMT_DIAG_PART_LD] = old[j] + dqp[j];
+            }
+        }
+        FB_STAMP(6);                                    // dQ accumulation
+        qt = qn;
+    };
+    body(std::true_type{}, std::true_type{});           // nt >= 2 (attn_bwd_fused_ok: nt > 8)
+    for (int t = 1; t < nt - 1; ++t) body(std::false_type{}, std::true_type{});
+    body(std::false_type{}, std::false_type{});
+#ifdef MMT_ABLATIONS
+    if (STAMP && g_attn_stamps && lane == 0) {
+        unsigned long long t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+        unsigned long long* q = g_attn_stamps + ((size_t)blockIdx.x * NW + wave) * 16;
+        for (int i = 0; i < 7; ++i) q[i] = st_acc[i];
+        q[7] = t1 - st_entry; q[9] = live ? 1 : 2;
+    }
+#endif
+    lds_barrier();                                      // every accumulator is complete
+    if (!live) return;
+    {   // dQ of query tile `kt` (any one tile per wave): lanes 2q and 2q + 1 own query q, features 0..7 and 8..15: 32 contiguous bytes
+        // per query row.  Accumulator word of (e, q): register (e&3) + 4*(e>>3), lane q + 32*((e>>2)&1).
+        const int q = lane >> 1, half = lane & 1, t = kt * 32 + q;
+        const float* slot = dqacc0 + (size_t)kt * (MMT_DIAG_ACC_BYTES / 4);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = slot[((i & 3) + 4 * half) * MMT_DIAG_PART_LD + q + 32 * ((i >> 2) & 1)];
+        if (t < T) {
+            const float rm = rowmask ? rowmask[m0 + t] : 1.f;
+            const float sc = (rm == 0.0f) ? 0.f : scale;                        // blanked query rows pass no gradient to Q
+            bf16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (bf16)(v[i] * sc);
+            *reinterpret_cast<bf16x8*>(dqkv + (size_t)(m0 + t) * lddkv + head * DKP + 8 * half) = o;
+        }
+    }
+    // dK = ln2 * acc rows 16.. (scores are in the log2 domain), dV = acc rows 0..15; column key = r
+    const float LN2 = 0.6931471805599453f;
+    const int t = kt * 32 + r;
+    if (t < T) {
+        const size_t m = (size_t)m0 + t;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            bf16x4 kv, vv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { kv[j] = (bf16)(acc[8 + 4 * g + j] * LN2); vv[j] = (bf16)acc[4 * g + j]; }
+            const int e0 = head * DKP + 8 * g + 4 * hh;
+            *reinterpret_cast<bf16x4*>(dqkv + m * lddkv + HD + e0) = kv;
+            *reinterpret_cast<bf16x4*>(dqkv + m * lddkv + 2 * HD + e0) = vv;
+        }
+    }
+}

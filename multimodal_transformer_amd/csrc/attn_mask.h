@@ -84,6 +84,7 @@ struct MaskGenParams {
     int nbh, nt, nlayers;
     uint32_t thr16;
     uint32_t s0[16], s1[16];               // stream keys of the layers' attention dropout (make_drop(p, seed, 4l+0))
+    const uint64_t* seedword;              // non-null: device-resident seed (common.h drop_resolve); s0[l] then holds the stream id 4l+0
 };
 
 // rows[x] = 32 bits over the lane index (x = the register-side index): the 64 lane words of one block, 8 x 16 bytes, into this lane's
@@ -119,7 +120,7 @@ __device__ __forceinline__ void attn_mask_gen_block(const MaskGenParams& P, int 
     const int bh = (int)(gc / per_bh);
     const int rem = (int)(gc - (size_t)bh * per_bh), qt = rem / P.nt, kt = rem - qt * P.nt;
     DropCfg base; base.thr16 = P.thr16; base.scale = 1.f; base.s0 = P.s0[layer]; base.s1 = P.s1[layer];
-    const DropCfg dc = drop_substream(base, (uint32_t)bh);
+    const DropCfg dc = drop_substream(drop_resolve(base, P.seedword), (uint32_t)bh);
     uint32_t W[32];
     attn_keep_block(dc, (uint32_t)(qt * P.nt + kt), W);                    // W[key] bit query
     uint16_t* const mine = patch[wave] + lane * MMT_MASK_LDS_ROW;

@@ -147,10 +147,35 @@ __host__ __device__ inline uint64_t splitmix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-__host__ __device__ inline DropCfg make_drop(float p, uint64_t seed, uint32_t stream) {
+// Device-resident seeds.  A step that is replayed from a hipGraph cannot take its seed by value (it would be frozen at capture): the
+// forward's first kernel (seed_advance_kernel) copies the caller's 64-bit seed state into the workspace's seed word and advances the
+// state, and every kernel of that forward AND of its backward derives its stream keys from the seed word.  Such a kernel receives a
+// DropCfg whose s0 holds the STREAM ID (s1 = 0) next to the pointer; drop_resolve() turns it into the same keys make_drop() gives on
+// the host for (seed, stream), so mmt_debug_dropout_mask(seed value, stream) replays a device-seeded mask too.
+__device__ __forceinline__ DropCfg drop_resolve(DropCfg c, const uint64_t* __restrict__ seedword) {
+    if (seedword && c.thr16) {
+        const uint64_t k = splitmix64(splitmix64(*seedword) + 0x100000001B3ull * (uint64_t)c.s0);
+        c.s0 = (uint32_t)k;
+        c.s1 = (uint32_t)(k >> 32);
+    }
+    return c;
+}
+// state[0]: the seed the NEXT train-mode forward uses.  One thread: seed word <- state, state <- splitmix64(state).
+__global__ void seed_advance_kernel(uint64_t* __restrict__ state, uint64_t* __restrict__ seedword) {
+    const uint64_t s = state[0];
+    seedword[0] = s;
+    state[0] = splitmix64(s);
+}
+// `bits`: resolution of the drop probability, P(drop) = round(p * 2^bits) / 2^bits.  16 for the streams that compare a 16-bit hash half
+// with the threshold; 12 for the attention-probability stream, whose bit-parallel generator (attn_mask.h) spends one hash word per
+// threshold bit above the lowest set one: p = 0.1 -> 410/4096 = 0.100098 with 11 words per 32 decisions instead of 15 (thr16 =
+// 0x199A).  The scale of the kept values is always that of the probability actually used, so the estimator stays unbiased.
+__host__ __device__ inline DropCfg make_drop(float p, uint64_t seed, uint32_t stream, int bits = 16) {
     DropCfg c;
-    double t = (double)p * 65536.0 + 0.5;
-    c.thr16 = p <= 0.f ? 0u : (t >= 65535.0 ? 65535u : (uint32_t)t);
+    const double q = (double)(1u << bits);
+    double t = (double)p * q + 0.5;
+    c.thr16 = p <= 0.f ? 0u : (t >= q - 1.0 ? (uint32_t)(q - 1.0) : (uint32_t)t) << (16 - bits);
+    if (p > 0.f && c.thr16 == 0u) c.thr16 = 1u << (16 - bits);          // a positive p never rounds to "off"
     c.scale = 65536.0f / (65536.0f - (float)c.thr16);
     const uint64_t k = splitmix64(splitmix64(seed) + 0x100000001B3ull * (uint64_t)stream);
     c.s0 = (uint32_t)k;

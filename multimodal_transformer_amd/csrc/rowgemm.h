@@ -92,6 +92,8 @@ struct RowGemmParams {
     DropCfg next_drop; int next_lda;       // KEEP_AS: the next stage's A tile = bf16(drop(out)) is left in As with this row stride
     // ---- K-chunked A staging (bf16 A from global): only `kchunk` (a power of two >= 64) columns of the A tile are in LDS at a time
     int kchunk;                            // 0: the whole K
+    // ---- device-resident dropout seed (common.h drop_resolve): non-null = the DropCfg fields above carry stream ids, not keys
+    const uint64_t* seedword;
 };
 
 __host__ __device__ inline int rowgemm_fw(int EPI, bool lnpro, int KP, int NP) {
@@ -155,6 +157,8 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     constexpr int ROWS = MMT_ROWS, TPR = MMT_RTPR, MT = MMT_ROWS / 16;
     const int m0 = blockIdx.x * ROWS;
     const int l15 = lane & 15, lq = lane >> 4;
+    const DropCfg a_drop = drop_resolve(p.a_drop, p.seedword), e_drop = drop_resolve(p.drop, p.seedword),
+                  next_drop = drop_resolve(p.next_drop, p.seedword);      // wave-uniform: scalar registers
     PHASE_DECL
 
     // W fragments (straight from L2, ~1k cycles away) travel through a ring of PFD k-blocks per wave.  The first PFD blocks of the
@@ -243,11 +247,11 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             bf16x4 o = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
             if (m < M && c < K) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(Xs + row * sm.ldx + c);
-                if (p.a_drop.thr16) {
+                if (a_drop.thr16) {
 #pragma unroll
                     for (int i = 0; i < 4; i += 2) {
-                        const uint32_t w = drop_pair(p.a_drop, (uint64_t)m * KP + c + i);
-                        v[i] = drop_lo(p.a_drop, w, v[i]); v[i + 1] = drop_hi(p.a_drop, w, v[i + 1]);
+                        const uint32_t w = drop_pair(a_drop, (uint64_t)m * KP + c + i);
+                        v[i] = drop_lo(a_drop, w, v[i]); v[i + 1] = drop_hi(a_drop, w, v[i + 1]);
                     }
                 }
 #pragma unroll
@@ -265,11 +269,11 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             bf16x4 o = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
             if (m < M && c < K) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(A + (size_t)m * p.lda + c);
-                if (p.a_drop.thr16) {
+                if (a_drop.thr16) {
 #pragma unroll
                     for (int i = 0; i < 4; i += 2) {
-                        const uint32_t w = drop_pair(p.a_drop, (uint64_t)m * KP + c + i);
-                        v[i] = drop_lo(p.a_drop, w, v[i]); v[i + 1] = drop_hi(p.a_drop, w, v[i + 1]);
+                        const uint32_t w = drop_pair(a_drop, (uint64_t)m * KP + c + i);
+                        v[i] = drop_lo(a_drop, w, v[i]); v[i + 1] = drop_hi(a_drop, w, v[i + 1]);
                     }
                 }
 #pragma unroll
@@ -397,11 +401,11 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
 #pragma unroll
                         for (int i = 0; i < 4; ++i) x[i] = ((float)mk[it][i] > 0.f) ? x[i] * p.mask_scale : 0.f;
                     }
-                    if (p.drop.thr16) {
+                    if (e_drop.thr16) {
 #pragma unroll
                         for (int i = 0; i < 4; i += 2) {
-                            const uint32_t w = drop_pair(p.drop, (uint64_t)m * NP + n + i);
-                            x[i] = drop_lo(p.drop, w, x[i]); x[i + 1] = drop_hi(p.drop, w, x[i + 1]);
+                            const uint32_t w = drop_pair(e_drop, (uint64_t)m * NP + n + i);
+                            x[i] = drop_lo(e_drop, w, x[i]); x[i + 1] = drop_hi(e_drop, w, x[i + 1]);
                         }
                     }
                     x += res[it];
@@ -573,11 +577,11 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                     if (KEEP & KEEP_X) *reinterpret_cast<f32x4*>(Xs + row * sm.ldx + c) = o;
                 }
                 if (KEEP & KEEP_AS) {        // the next stage's A tile: bf16 of the (dropped) gradient, zero in the pads and in rows >= M
-                    if (p.next_drop.thr16 && live && c < d) {
+                    if (next_drop.thr16 && live && c < d) {
 #pragma unroll
                         for (int i = 0; i < 4; i += 2) {
-                            const uint32_t w = drop_pair(p.next_drop, (uint64_t)m * NP + c + i);
-                            o[i] = drop_lo(p.next_drop, w, o[i]); o[i + 1] = drop_hi(p.next_drop, w, o[i + 1]);
+                            const uint32_t w = drop_pair(next_drop, (uint64_t)m * NP + c + i);
+                            o[i] = drop_lo(next_drop, w, o[i]); o[i + 1] = drop_hi(next_drop, w, o[i + 1]);
                         }
                     }
                     bf16x4 o16;

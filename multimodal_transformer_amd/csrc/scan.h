@@ -439,7 +439,9 @@ __global__ void mfn_prep_kernel(const float* __restrict__ Wm, const float* __res
 __global__ __launch_bounds__(512) void mfn_mem_scan_fwd_kernel(
         const float* __restrict__ apre, const float* __restrict__ chat, const bf16* __restrict__ WmF,
         const bf16* __restrict__ W2F, const float* __restrict__ b2,
-        float* __restrict__ mem_all, float* __restrict__ u_all, float* __restrict__ g_all, int T, int B, int BT, DropCfg drop) {
+        float* __restrict__ mem_all, float* __restrict__ u_all, float* __restrict__ g_all, int T, int B, int BT, DropCfg drop_in,
+        const uint64_t* __restrict__ seedword) {
+    const DropCfg drop = drop_resolve(drop_in, seedword);
     __shared__ __attribute__((aligned(16))) bf16 membuf[16 * (MFN_MD + 8)];
     __shared__ __attribute__((aligned(16))) bf16 ubuf[16 * (MFN_U + 8)];
     constexpr int LDM = MFN_MD + 8, LDU = MFN_U + 8;

@@ -40,8 +40,12 @@ class _EncoderStackFn(torch.autograd.Function):
             _lib.check(lib.mmt_encoder_forward(None, None, None, None, None, 0, B, T, d, h, d_ff, n_layers, eps, 0.0, 0, None))
         ws = _lib.POOL.get(nbytes, x_.device, tag=("encoder", B, T, d, h, d_ff, n_layers, train))
         y = torch.empty_like(x_)
-        _lib.check(lib.mmt_encoder_forward(_lib.ptr(x_), _lib.ptr(m_), _lib.ptr(p_), _lib.ptr(y), _lib.ptr(ws), nbytes,
-                                           B, T, d, h, d_ff, n_layers, eps, dropout_p, seed, _lib.stream_ptr()))
+        if isinstance(seed, _lib.DeviceSeed):        # device-resident seed: read and advanced by the launch itself (hipGraph replays)
+            _lib.check(lib.mmt_encoder_forward_devseed(_lib.ptr(x_), _lib.ptr(m_), _lib.ptr(p_), _lib.ptr(y), _lib.ptr(ws), nbytes,
+                                                       B, T, d, h, d_ff, n_layers, eps, dropout_p, seed.ptr(), _lib.stream_ptr()))
+        else:
+            _lib.check(lib.mmt_encoder_forward(_lib.ptr(x_), _lib.ptr(m_), _lib.ptr(p_), _lib.ptr(y), _lib.ptr(ws), nbytes,
+                                               B, T, d, h, d_ff, n_layers, eps, dropout_p, seed, _lib.stream_ptr()))
         needs_bwd = _needs or any(ctx.needs_input_grad)
         if needs_bwd:
             ctx.save_for_backward(x_, m_, p_)
@@ -61,16 +65,26 @@ class _EncoderStackFn(torch.autograd.Function):
         dy_ = _f32c(dy)
         dx = torch.empty_like(x_)
         dp = torch.empty_like(p_)           # fresh buffer per call: returned gradient views never alias later calls
-        _lib.check(lib.mmt_encoder_backward(_lib.ptr(dy_), _lib.ptr(x_), _lib.ptr(m_), _lib.ptr(p_), _lib.ptr(dx), _lib.ptr(dp),
-                                            _lib.ptr(ctx.ws), nbytes, B, T, d, h, d_ff, n_layers, eps, dropout_p, seed,
-                                            _lib.stream_ptr()))
+        if isinstance(seed, _lib.DeviceSeed):        # the forward left its seed in the workspace
+            _lib.check(lib.mmt_encoder_backward_devseed(_lib.ptr(dy_), _lib.ptr(x_), _lib.ptr(m_), _lib.ptr(p_), _lib.ptr(dx), _lib.ptr(dp),
+                                                        _lib.ptr(ctx.ws), nbytes, B, T, d, h, d_ff, n_layers, eps, dropout_p,
+                                                        _lib.stream_ptr()))
+        else:
+            _lib.check(lib.mmt_encoder_backward(_lib.ptr(dy_), _lib.ptr(x_), _lib.ptr(m_), _lib.ptr(p_), _lib.ptr(dx), _lib.ptr(dp),
+                                                _lib.ptr(ctx.ws), nbytes, B, T, d, h, d_ff, n_layers, eps, dropout_p, seed,
+                                                _lib.stream_ptr()))
         _lib.POOL.put(ctx.ws)
         ctx.ws = None
         return dx, None, dp, None, None, None, None, None, None
 
 
+def _seed_arg(seed):
+    return seed if isinstance(seed, _lib.DeviceSeed) else int(seed)
+
+
 def encoder_stack(x, mask, flat_params, h, d_ff, n_layers, eps=1e-6, dropout_p=0.0, seed=0):
-    return _EncoderStackFn.apply(x, mask, flat_params, int(h), int(d_ff), int(n_layers), float(eps), float(dropout_p), int(seed))
+    """``seed``: a python int (by value) or a ``_lib.DeviceSeed`` (device-resident: fresh masks at every hipGraph replay)."""
+    return _EncoderStackFn.apply(x, mask, flat_params, int(h), int(d_ff), int(n_layers), float(eps), float(dropout_p), _seed_arg(seed))
 
 
 class _EncoderStackParamsFn(torch.autograd.Function):
@@ -112,7 +126,7 @@ class _Ctx:
 
 
 def encoder_stack_params(x, mask, params, h, d_ff, n_layers, eps=1e-6, dropout_p=0.0, seed=0, flat=None):
-    return _EncoderStackParamsFn.apply(x, mask, int(h), int(d_ff), int(n_layers), float(eps), float(dropout_p), int(seed), flat, *params)
+    return _EncoderStackParamsFn.apply(x, mask, int(h), int(d_ff), int(n_layers), float(eps), float(dropout_p), _seed_arg(seed), flat, *params)
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -375,9 +389,14 @@ class _MfnMemScanFn(torch.autograd.Function):
         mem_all = torch.empty(T, B, MD, dtype=torch.float32, device=dev)
         u_all = torch.empty(T, B, U, dtype=torch.float32, device=dev)
         g_all = torch.empty(T, B, 2 * MD, dtype=torch.float32, device=dev)
-        _lib.check(lib.mmt_mfn_mem_scan_forward(_lib.ptr(a_), _lib.ptr(c_), _lib.ptr(Wm_), _lib.ptr(W2_), _lib.ptr(b2_), _lib.ptr(mem_all),
-                                                _lib.ptr(u_all), _lib.ptr(g_all), _lib.ptr(ws), nbytes, T, B, MD, HG,
-                                                dropout_p, seed, _lib.stream_ptr()))
+        if isinstance(seed, _lib.DeviceSeed):
+            _lib.check(lib.mmt_mfn_mem_scan_forward_devseed(_lib.ptr(a_), _lib.ptr(c_), _lib.ptr(Wm_), _lib.ptr(W2_), _lib.ptr(b2_), _lib.ptr(mem_all),
+                                                            _lib.ptr(u_all), _lib.ptr(g_all), _lib.ptr(ws), nbytes, T, B, MD, HG,
+                                                            dropout_p, seed.ptr(), _lib.stream_ptr()))
+        else:
+            _lib.check(lib.mmt_mfn_mem_scan_forward(_lib.ptr(a_), _lib.ptr(c_), _lib.ptr(Wm_), _lib.ptr(W2_), _lib.ptr(b2_), _lib.ptr(mem_all),
+                                                    _lib.ptr(u_all), _lib.ptr(g_all), _lib.ptr(ws), nbytes, T, B, MD, HG,
+                                                    dropout_p, seed, _lib.stream_ptr()))
         ctx.save_for_backward(c_, Wm_, W2_, mem_all, u_all, g_all)
         ctx.dims = (T, B, U, MD, HG, nbytes)
         ctx.dropout_p = dropout_p
@@ -421,7 +440,7 @@ class _MfnMemScanFn(torch.autograd.Function):
 
 
 def mfn_mem_scan(apre, chat, Wm, W2, b2, dropout_p=0.0, seed=0):
-    return _MfnMemScanFn.apply(apre, chat, Wm, W2, b2, float(dropout_p), int(seed))
+    return _MfnMemScanFn.apply(apre, chat, Wm, W2, b2, float(dropout_p), _seed_arg(seed))
 
 
 class _MseSumLossFn(torch.autograd.Function):

@@ -216,7 +216,7 @@ class Encoder(nn.Module):
             return self.norm(x)
         l0 = self.layers[0]
         p = l0.sublayer[0].dropout.p if self.training else 0.0
-        seed = _lib.next_dropout_seed(x.device, 1) if p > 0.0 else 0
+        seed = _lib.next_dropout_seed(x.device, 1, holder=self) if p > 0.0 else 0
         ps = self.flat_parameters()
         return F_hip.encoder_stack_params(x, mask, ps, l0.self_attn.h, l0.feed_forward.w_1.weight.shape[0],
                                           len(self.layers), eps=self.norm.eps, dropout_p=p, seed=seed,
@@ -311,7 +311,7 @@ class MFN(nn.Module):
         pg = self.gamma1_dropout.p if self.training else 0.0        # gamma dropout runs inside the memory scan
         if self.training and self.gamma2_dropout.p != self.gamma1_dropout.p:
             raise NotImplementedError("MFN: gamma1_dropout and gamma2_dropout must share one probability")
-        seed = _lib.next_dropout_seed(self.device, 2) if pg > 0.0 else 0
+        seed = _lib.next_dropout_seed(self.device, 2, holder=self) if pg > 0.0 else 0
         hs, c_prev, c_new = [], [], []
         main, streams = _MOD_STREAMS.begin(self.device, len(self.mods))
         for mod, st in zip(self.mods, streams):

@@ -176,8 +176,9 @@ def test_attention_mask_statistics(dev):
         k4, _ = F.dropout_mask(p, 42, 4, n, dev, attn_Tp=Tp)
         assert torch.equal(k1, k2)
         frac = 1 - k1.float().mean().item()
-        assert abs(frac - p) < 4 * np.sqrt(p * (1 - p) / n) + 2e-5
-        assert abs(s1 - 1 / (1 - round(p * 65536) / 65536)) < 1e-6
+        pq = round(p * 4096) / 4096                                 # the attention stream resolves p to 12 bits (common.h make_drop)
+        assert abs(pq - p) < 1.3e-4 and abs(frac - pq) < 4 * np.sqrt(p * (1 - p) / n) + 2e-5
+        assert abs(s1 - 1 / (1 - pq)) < 1e-6                        # kept values are scaled by the probability actually used
         for other in (k3, k4):
             agree = (k1 == other).float().mean().item()
             assert abs(agree - (p * p + (1 - p) * (1 - p))) < 6e-3
@@ -207,3 +208,67 @@ def test_multi_headed_attention_module_train_mode(dev):
     assert ctx.shape == (2, 8, 40, 16) and torch.isfinite(ctx).all()
     mha.eval()
     assert torch.equal(mha(x, x, x, mask), mha(x, x, x, mask))
+
+
+def test_device_resident_seed_fresh_masks_per_graph_replay(dev):
+    """A train step captured into a hipGraph must draw NEW masks at every replay (the reference's nn.Dropout does every step:
+    transformer/MFT/multiTransformer.py:17,45,101, transformer/SFT/train.py:131-141).  Under capture the encoder takes its seed from
+    device memory (mmt_encoder_forward_devseed): the seed state is peeked before each replay, the replays must differ from each other,
+    and the masks rebuilt from the peeked value reproduce that replay — forward, input gradient and parameter gradients — through the oracle."""
+    MT = mta().multiTransformer
+    d, h, n, B, T, lengths, p = 128, 8, 2, 2, 300, [300, 170], 0.1            # T = 300: the one-kernel attention backward
+    enc = MT.Encoder(MT.EncoderLayer(d, MT.MultiHeadedAttention(h, d), MT.PositionwiseFeedForward(d, R.D_FF, p), p), n)
+    p32 = R.gen_params(R.shapes_of(enc.state_dict()), 47)
+    enc.load_state_dict(p32)
+    enc = enc.to(dev).train()
+    params = list(enc.parameters())
+    x = R.gen_normal("devseed:x", (B, T, d), 47)
+    g = R.gen_normal("devseed:g", (B, T, d), 47)
+    mask = R.prefix_mask(lengths, T)
+    xg = x.to(dev).requires_grad_()
+    gd, md = g.to(dev), mask.to(dev)
+    out = {}
+
+    def step():
+        for q in params:
+            q.grad = None
+        xg.grad = None
+        y = enc(xg, md)
+        (y * gd).sum().backward()
+        out["y"] = y
+
+    with pytest.raises(RuntimeError, match="warm-up"):                        # a capture needs the seed state to exist beforehand
+        fresh = MT.Encoder(MT.EncoderLayer(d, MT.MultiHeadedAttention(h, d), MT.PositionwiseFeedForward(d, R.D_FF, p), p), 1).to(dev).train()
+        gtmp = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gtmp):
+            fresh(xg.detach(), md)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            step()                                                            # eager warm-up: by-value seeds, creates the DeviceSeed
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    results = []
+    for _ in range(2):
+        seed = enc._dev_seed.peek()                                           # the seed this replay is going to use
+        graph.replay()
+        torch.cuda.synchronize()
+        assert enc._dev_seed.peek() != seed                                   # the launch advanced it
+        results.append((seed, out["y"].detach().clone(), xg.grad.detach().clone(),
+                        torch.cat([q.grad.reshape(-1) for q in enc.flat_parameters()]).clone()))
+    assert float((results[0][1] - results[1][1]).abs().max()) > 1e-2          # different masks in the two replays
+    seed, y, dx, dflat = results[1]
+    drops = _masks(dev, p, seed, n, B, T, d, h, R.D_FF)
+    pd = {k: v.double().clone().requires_grad_() for k, v in p32.items()}
+    xd = x.double().clone().requires_grad_()
+    ref = oracle.encoder_stack(pd, "", xd, mask.double(), h, drops)
+    (ref * g.double()).sum().backward()
+    assert _report("devseed out", y.cpu(), ref.detach()) < OUT_RTOL
+    assert _report("devseed dx", dx.cpu(), xd.grad) < RELU_GRAD_RTOL
+    ref_flat = torch.cat([pd[k].grad.reshape(-1) for k in _flat_names(n)])
+    assert _report("devseed dparams", dflat.cpu(), ref_flat) < RELU_GRAD_RTOL

@@ -311,7 +311,8 @@ def test_evaluate_loop_matches_per_sequence_oracle(dev):
         def forward(self, data, lengths, mask):
             return self.m(data["fused"], mask, lengths)
 
-    stats = batching.evaluate(Wrap(model), {"fused": x.numpy()}, tgt.numpy(), lengths, device=dev)
+    stats = batching.evaluate(Wrap(model).eval(), {"fused": x.numpy()}, tgt.numpy(), lengths, device=dev)
+    assert not model.training                            # evaluate() restores the mode it found
     cccs, sq, unpadded = [], 0.0, {}
     for i, L in enumerate(lengths):
         yo = oracle.nlp_transformer(p32, x[i:i + 1, :L], R.prefix_mask([L], L), 4)[0, :, 0].detach().numpy()

@@ -120,3 +120,51 @@ def test_flat_adam_matches_torch_adam(dev):
         opt_ref.step()
     for (k, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()):
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6, k
+
+
+def test_flat_adam_state_dict_round_trip(dev):
+    """optimizer.state_dict() / load_state_dict() of FlatAdam carry the moments and the per-parameter step counts, in torch.optim.Adam's
+    own format: a run resumed from a checkpoint continues exactly (no lr kick from re-started bias corrections), and the two optimisers
+    read each other's checkpoints.  (The reference saves only the model, transformer/SFT/train.py:342-344; resuming the optimiser is what
+    torch users expect of a drop-in.)"""
+    import copy
+    from multimodal_transformer_amd import functional as F, multiTransformer as MT
+    from multimodal_transformer_amd.optim import FlatAdam
+    model = MT.NLPTransformer(512, embed_dim=64, h=4, N=2, device=dev)
+    model.load_state_dict(R.gen_params(R.shapes_of(model.state_dict()), 41))
+    model = model.to(dev).eval()
+    lengths = [20, 13, 6]
+    mask = R.prefix_mask(lengths, 20).to(dev)
+
+    def grads(m, i):
+        x = torch.tanh(R.gen_normal("fasd:x%d" % i, (3, 20, 512), 41)).to(dev)
+        tgt = (R.gen_uniform("fasd:t%d" % i, (3, 20, 1), 41) * R.prefix_mask(lengths, 20)).to(dev)
+        for q in m.parameters():
+            q.grad = None
+        F.mse_sum_loss_backward(m(x, mask, lengths), tgt, sum(lengths))
+
+    opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=1e-2)
+    for i in range(3):
+        grads(model, i)
+        opt.step()
+    sd = copy.deepcopy(opt.state_dict())
+    assert len(sd["state"]) > 30 and all(float(v["step"]) == 3.0 for v in sd["state"].values())
+    assert all(float(v["exp_avg_sq"].abs().sum()) > 0 for v in sd["state"].values())
+    twin, twin_t = copy.deepcopy(model), copy.deepcopy(model)
+    opt2 = FlatAdam(twin.parameters(), lr=1e-3, weight_decay=1e-2)
+    opt2.load_state_dict(copy.deepcopy(sd))                              # FlatAdam -> FlatAdam (a copy each: torch keeps the CPU step tensors it is handed)
+    opt_t = torch.optim.Adam(twin_t.parameters(), lr=1e-3, weight_decay=1e-2)
+    opt_t.load_state_dict(copy.deepcopy(sd))                             # FlatAdam -> torch.optim.Adam
+    for i in range(3, 5):
+        grads(model, i)
+        for m in (twin, twin_t):
+            for pm, pr in zip(model.parameters(), m.parameters()):       # the same gradients for all three
+                pr.grad = None if pm.grad is None else pm.grad.clone()
+        opt.step(); opt2.step(); opt_t.step()
+    for (k, a), (_, b), (_, c) in zip(model.state_dict().items(), twin.state_dict().items(), twin_t.state_dict().items()):
+        assert torch.equal(a, b), k                                      # resumed run == uninterrupted run, bit for bit
+        assert rel_l2(a.cpu().numpy(), c.cpu().numpy()) < 2e-6, k
+    # torch.optim.Adam -> FlatAdam
+    opt3 = FlatAdam(copy.deepcopy(twin_t).parameters(), lr=1e-3, weight_decay=1e-2)
+    opt3.load_state_dict(copy.deepcopy(opt_t.state_dict()))
+    assert all(float(v["step"]) == 5.0 for v in opt3.state_dict()["state"].values())

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool: where does attn_bwd_fused16_kernel<train> spend its tile time?  Needs tools/bin/libmmt_abl.so (built with
+"""Developer tool: where does attn_bwd_diag16_kernel<train> spend its tile time?  Needs tools/bin/libmmt_abl.so (built with
 -DMMT_ABLATIONS); runs the configs[3] encoder forward+backward with the stamped variant of the kernel (MMT_ABL=7)."""
 import ctypes
 import os
@@ -13,8 +13,8 @@ import numpy as np
 import torch
 from multimodal_transformer_amd import multiTransformer as MT, _lib
 
-SEG = ["loop top (prefetch issue)", "exp + dropout + dS", "packs + dV/dK MFMAs + patch writes", "patch reads + dQ MFMA + partial writes",
-       "next tile: row constants, operand reads, score MFMAs", "staging store + barrier", "dQ reduction + store"]
+SEG = ["loop top", "exp + dropout + dS", "packs + dV/dK MFMAs + patch writes", "patch reads + dQ MFMA",
+       "next tile: row constants, operand reads, score MFMAs", "barrier", "dQ accumulation (LDS read-add-write)"]
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 B, T, d, h = 32, 500, 128, 8
@@ -32,8 +32,8 @@ _lib.profile(True)
 for _ in range(5):
     enc(x, mask).sum().backward()
 torch.cuda.synchronize()
-ms, n = _lib.profile_collect()["attn_bwd_fused16_kernel"]
-print("attn_bwd_fused16 (stamped) %.2f us/launch" % (1e3 * ms / n))
+ms, n = _lib.profile_collect()["attn_bwd_diag16_kernel"]
+print("attn_bwd_diag16 (stamped) %.2f us/launch" % (1e3 * ms / n))
 full = stamps.cpu().numpy().reshape(-1, 16).astype(float)
 live = full[full[:, 9] == 1]
 life = live[:, 7]
