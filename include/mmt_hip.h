@@ -130,6 +130,39 @@ int mmt_linear_backward(const float* dy, const float* x, const float* W, const f
                         float* dx, float* dW, float* db,
                         void* workspace, size_t workspace_bytes, int M, int K, int N, int act, mmt_stream_t stream);
 
+/* ... with train-mode dropout fused in: on the INPUT (x -> drop(x) while the A tile is staged: the `Dropout(0.1) -> Linear -> ReLU` embed of
+ * NLPTransformer, transformer/SFT/multiTransformer.py:431-433,461) and / or behind the ReLU (act must be 1: MFN's out_dropout on
+ * relu(out_fc1), transformer/MFT/multiTransformer.py:244-245).  Streams 2000 (input, index m*KP + k, KP = K rounded up to 64) and 2001
+ * (output, index m*NP + n) of mmt_debug_dropout_mask.  seed_state: NULL (seed by value) or a device-resident seed as in
+ * mmt_encoder_forward_devseed; the backward then passes device_seeded = 1 (the seed sits in the workspace) and any seed. */
+int mmt_linear_dropout_forward(const float* x, const float* W, const float* b, const float* rowscale, float* y,
+                               void* workspace, size_t workspace_bytes, int M, int K, int N, int act,
+                               float in_dropout_p, float out_dropout_p, uint64_t seed, uint64_t* seed_state, mmt_stream_t stream);
+int mmt_linear_dropout_backward(const float* dy, const float* x, const float* W, const float* y, const float* rowscale,
+                                float* dx, float* dW, float* db,
+                                void* workspace, size_t workspace_bytes, int M, int K, int N, int act,
+                                float in_dropout_p, float out_dropout_p, uint64_t seed, int device_seeded, mmt_stream_t stream);
+
+/* ---- Data movement between the kernels of a sequence model, so that its forward and backward run no library kernel: up to any number of
+ * strided 2-D fp32 copies per call (24 per launch).  Replaces the torch.cat / stack / permute / slicing / broadcasting glue of
+ * MFN.forward (cStar = [c_{t-1}; c_t] :212-217, [h; mem] :241-243), MultiTransformer.forward (permute :300, `* mask` :310) and of the SFT decoder
+ * (transformer/SFT/multiTransformer.py:463-483) and their autograd twins.
+ * dst[perm(r)][c] (+)= rowscale[.] * (src[r][c] + src2[r][c]) for r < rows, c < cols.  src NULL: zeros; src2 optional; a stride of 0
+ * broadcasts one row; perm 1: source rows are batch-major (b*T+t), destination rows time-major (t*B+b); perm 2: the reverse; rowscale is
+ * indexed by the batch-major row under a permutation.  Segments of one call must not overlap in their destinations. */
+typedef struct {
+    const float* src; const float* src2; float* dst; const float* rowscale;
+    int rows, cols, src_ld, src2_ld, dst_ld, perm, pB, pT, accumulate;
+} mmt_copy_seg;
+int mmt_copy2d(const mmt_copy_seg* host_segs, int nsegs, mmt_stream_t stream);
+
+/* attended = softmax(logits, over the N features) * v, att kept for the backward.   Replaces transformer/MFT/multiTransformer.py:218-219
+ * backward: dlogits = att * (dout * v - sum_n dout v att), dv = dout * att. */
+int mmt_softmax_mul_forward(const float* logits, const float* v, float* att, float* out, int M, int N, mmt_stream_t stream);
+int mmt_softmax_mul_backward(const float* dout, const float* att, const float* v, float* dlogits, float* dv, int M, int N, mmt_stream_t stream);
+/* out[c] = sum over `rows` rows of x (row stride ld): gradient of a row that the forward broadcast over the batch. */
+int mmt_colsum(const float* x, float* out, int rows, int cols, int ld, mmt_stream_t stream);
+
 /* ---- LSTM recurrence over T steps with the input projection already applied.
  * Replaces the per-step nn.LSTMCell loop of MFN.forward       transformer/MFT/multiTransformer.py:200-208
  * and the per-step nn.LSTM call of the SFT decoder            transformer/SFT/multiTransformer.py:471-476.

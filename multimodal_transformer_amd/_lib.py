@@ -41,6 +41,12 @@ SIGNATURES = {
     "mmt_linear_workspace_bytes": (_SZ, [_I] * 3),
     "mmt_linear_forward": (_I, [_P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_P]),
     "mmt_linear_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_P]),
+    "mmt_linear_dropout_forward": (_I, [_P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_F, _F, _U64, _P, _P]),
+    "mmt_linear_dropout_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ] + [_I] * 4 + [_F, _F, _U64, _I, _P]),
+    "mmt_copy2d": (_I, [_P, _I, _P]),
+    "mmt_softmax_mul_forward": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "mmt_softmax_mul_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "mmt_colsum": (_I, [_P, _P, _I, _I, _I, _P]),
     "mmt_lstm_scan_workspace_bytes": (_SZ, [_I]),
     "mmt_lstm_scan_forward": (_I, [_P] * 8 + [_SZ] + [_I] * 3 + [_P]),
     "mmt_lstm_scan_backward": (_I, [_P] * 10 + [_SZ] + [_I] * 3 + [_P]),
@@ -58,6 +64,14 @@ SIGNATURES = {
     "mmt_debug_dropout_mask": (_I, [_F, _U64, _c.c_uint32, _U64, _c.c_uint32, _P, _P, _P]),
     "mmt_debug_poison_lds": (_I, [_c.c_uint32, _P, _P]),
 }
+
+
+
+class CopySeg(ctypes.Structure):
+    """mmt_copy_seg of include/mmt_hip.h"""
+    _fields_ = [("src", _P), ("src2", _P), ("dst", _P), ("rowscale", _P), ("rows", _I), ("cols", _I), ("src_ld", _I), ("src2_ld", _I),
+                ("dst_ld", _I), ("perm", _I), ("pB", _I), ("pT", _I), ("accumulate", _I)]
+
 
 _lib = None
 _lock = threading.Lock()

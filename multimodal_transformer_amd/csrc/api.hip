@@ -19,6 +19,7 @@
 #include "scan256.h"
 #include "scan_cluster.h"
 #include "convpool.h"
+#include "glue.h"
 
 // ------------------------------------------------------------------------------------ error plumbing
 static thread_local char g_err[512] = "";
@@ -909,7 +910,7 @@ __global__ void pad_f32_kernel(const float* __restrict__ src, float* __restrict_
 // g = dy * rowscale * act'(y) -> bf16 row-major [M][NP] (pad columns written as zeros): the A operand of the input-gradient GEMM and
 // of the weight-gradient kernel
 __global__ void grad_prep_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ rowscale,
-                                 int act, bf16* __restrict__ g, int M, int N, int NP) {
+                                 int act, bf16* __restrict__ g, int M, int N, int NP, float gscale) {      // gscale: 1/(1-p) of an output dropout (y > 0 <=> kept)
     const size_t total = (size_t)M * (NP >> 2);
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(idx / (NP >> 2)), n = (int)(idx % (NP >> 2)) * 4;
@@ -920,7 +921,7 @@ __global__ void grad_prep_kernel(const float* __restrict__ dy, const float* __re
             if (n + i < N) {
                 v = dy[(size_t)m * N + n + i];
                 if (rowscale) v *= rowscale[m];
-                if (act == 1) { if (!(y[(size_t)m * N + n + i] > 0.f)) v = 0.f; }
+                if (act == 1) { v = (y[(size_t)m * N + n + i] > 0.f) ? v * gscale : 0.f; }
                 else if (act == 2) { const float yy = y[(size_t)m * N + n + i]; v *= 1.f - yy * yy; }
                 else if (act == 3) { const float yy = y[(size_t)m * N + n + i]; v *= yy * (1.f - yy); }
             }
@@ -931,20 +932,34 @@ __global__ void grad_prep_kernel(const float* __restrict__ dy, const float* __re
 }
 
 // fp32 [M][K] -> bf16 row-major [M][KP] (pad columns written as zeros): the B operand of the weight-gradient kernel
-__global__ void cast_rows_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int M, int K, int KP) {
+// (`drop_in`: the input dropout of the forward, index m*KP + k, regenerated here)
+__global__ void cast_rows_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int M, int K, int KP, DropCfg drop_in,
+                                 const uint64_t* __restrict__ seedword) {
+    const DropCfg drop = drop_resolve(drop_in, seedword);
     const size_t total = (size_t)M * (KP >> 2);
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(idx / (KP >> 2)), k = (int)(idx % (KP >> 2)) * 4;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (k + i < K) ? src[(size_t)m * K + k + i] : 0.f;
+        if (drop.thr16) {
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                const uint32_t w = drop_pair(drop, (uint64_t)m * KP + k + i);
+                v[i] = drop_lo(drop, w, v[i]); v[i + 1] = drop_hi(drop, w, v[i + 1]);
+            }
+        }
         bf16x4 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (bf16)((k + i < K) ? src[(size_t)m * K + k + i] : 0.f);
+        for (int i = 0; i < 4; ++i) o[i] = (bf16)v[i];
         *reinterpret_cast<bf16x4*>(dst + (size_t)m * KP + k) = o;
     }
 }
 
-struct LinWs { bf16 *Wp, *WTp, *g, *xb; float *bp, *sW, *sb; int KP, NP, MP, M16, nsplit, mchunk; size_t bytes; };
+struct LinWs { uint64_t* seedword; bf16 *Wp, *WTp, *g, *xb; float *bp, *sW, *sb; int KP, NP, MP, M16, nsplit, mchunk; size_t bytes; };
 static void carve_linear(LinWs& W, int M, int K, int N, void* base) {
     Carver c(base);
+    W.seedword = c.take<uint64_t>(1);
     W.KP = round_up(K, 64); W.NP = round_up(N, 64); W.MP = round_up(M, 64); W.M16 = round_up(M, 16);
     const int tiles = (W.NP / 64) * (W.KP / 64);
     int s = (512 + tiles - 1) / tiles; if (s < 1) s = 1; if (s > 32) s = 32;
@@ -969,10 +984,19 @@ static int check_linear(int M, int K, int N) {
     return MMT_OK;
 }
 
-extern "C" int mmt_linear_forward(const float* x, const float* Wt, const float* b, const float* rowscale, float* y,
-                                  void* workspace, size_t workspace_bytes, int M, int K, int N, int act, mmt_stream_t stream) {
+#define MMT_LINEAR_IN_STREAM 2000      // dropout stream ids of the affine map's input / output dropout
+#define MMT_LINEAR_OUT_STREAM 2001
+static int check_linear_drop(float in_p, float out_p, int act) {
+    if (!(in_p >= 0.f && in_p < 1.f) || !(out_p >= 0.f && out_p < 1.f)) return fail(MMT_EINVAL, "dropout probability not in [0,1)");
+    if (out_p > 0.f && act != 1) return fail(MMT_EUNSUPPORTED, "output dropout is implemented behind ReLU only (the mask rides on y > 0)");
+    return MMT_OK;
+}
+static int linear_forward_impl(const float* x, const float* Wt, const float* b, const float* rowscale, float* y,
+                               void* workspace, size_t workspace_bytes, int M, int K, int N, int act,
+                               float in_p, float out_p, uint64_t seed, uint64_t* seed_state, mmt_stream_t stream) {
     int rc = check_linear(M, K, N);
     if (rc) return rc;
+    if ((rc = check_linear_drop(in_p, out_p, act))) return rc;
     if (!x || !Wt || !y || !workspace) return fail(MMT_EINVAL, "null pointer argument");
     LinWs W; carve_linear(W, M, K, N, workspace);
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
@@ -984,19 +1008,42 @@ extern "C" int mmt_linear_forward(const float* x, const float* Wt, const float* 
     p.M = M; p.K = K; p.KP = W.KP; p.N = N; p.NP = W.NP;
     p.A = x; p.lda = K; p.W = W.Wp; p.bias = W.bp; p.act = act; p.rowscale = rowscale;
     p.out_f32 = y; p.ldo = N;
+    const bool devseed = seed_state != nullptr && (in_p > 0.f || out_p > 0.f);
+    if (devseed) {
+        hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, st, seed_state, W.seedword);
+        LAUNCH_CHECK("seed_advance_kernel");
+        p.seedword = W.seedword;
+    }
+    p.a_drop = stream_drop(in_p, seed, MMT_LINEAR_IN_STREAM, devseed);        // x -> drop(x) as the A tile is staged (index m*KP + k)
+    p.drop = stream_drop(out_p, seed, MMT_LINEAR_OUT_STREAM, devseed);        // behind the activation (index m*NP + n)
     return launch_rowgemm<EPI_PLAIN, false>(p, st, S_LINEAR_FWD);
 }
+extern "C" int mmt_linear_forward(const float* x, const float* Wt, const float* b, const float* rowscale, float* y,
+                                  void* workspace, size_t workspace_bytes, int M, int K, int N, int act, mmt_stream_t stream) {
+    return linear_forward_impl(x, Wt, b, rowscale, y, workspace, workspace_bytes, M, K, N, act, 0.f, 0.f, 0, nullptr, stream);
+}
+extern "C" int mmt_linear_dropout_forward(const float* x, const float* Wt, const float* b, const float* rowscale, float* y,
+                                          void* workspace, size_t workspace_bytes, int M, int K, int N, int act,
+                                          float in_dropout_p, float out_dropout_p, uint64_t seed, uint64_t* seed_state, mmt_stream_t stream) {
+    return linear_forward_impl(x, Wt, b, rowscale, y, workspace, workspace_bytes, M, K, N, act, in_dropout_p, out_dropout_p, seed, seed_state, stream);
+}
 
-extern "C" int mmt_linear_backward(const float* dy, const float* x, const float* Wt, const float* y, const float* rowscale,
-                                   float* dx, float* dW, float* db,
-                                   void* workspace, size_t workspace_bytes, int M, int K, int N, int act, mmt_stream_t stream) {
+static int linear_backward_impl(const float* dy, const float* x, const float* Wt, const float* y, const float* rowscale,
+                                float* dx, float* dW, float* db,
+                                void* workspace, size_t workspace_bytes, int M, int K, int N, int act,
+                                float in_p, float out_p, uint64_t seed, bool devseed_in, mmt_stream_t stream) {
     int rc = check_linear(M, K, N);
     if (rc) return rc;
+    if ((rc = check_linear_drop(in_p, out_p, act))) return rc;
     if (!dy || !x || !Wt || !workspace || (act != 0 && !y)) return fail(MMT_EINVAL, "null pointer argument");
     LinWs W; carve_linear(W, M, K, N, workspace);
     if (workspace_bytes < W.bytes) return fail(MMT_EWORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, W.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(grad_prep_kernel, dim3(grid_for((size_t)M * (W.NP / 4))), dim3(256), 0, st, dy, y, rowscale, act, W.g, M, N, W.NP);
+    const bool devseed = devseed_in && (in_p > 0.f || out_p > 0.f);
+    const uint64_t* seedword = devseed ? W.seedword : nullptr;              // left there by the forward
+    const DropCfg in_drop = stream_drop(in_p, seed, MMT_LINEAR_IN_STREAM, devseed);
+    hipLaunchKernelGGL(grad_prep_kernel, dim3(grid_for((size_t)M * (W.NP / 4))), dim3(256), 0, st, dy, y, rowscale, act, W.g, M, N, W.NP,
+                       make_drop(out_p, 0, 0).scale);
     LAUNCH_CHECK("grad_prep_kernel");
     if (dx) {
         hipLaunchKernelGGL(pad_cast_kernel, dim3(grid_for((size_t)W.KP * W.NP)), dim3(256), 0, st, Wt, W.WTp, K, N, W.KP, W.NP, 1);
@@ -1005,10 +1052,11 @@ extern "C" int mmt_linear_backward(const float* dy, const float* x, const float*
         p.M = M; p.K = W.NP; p.KP = W.NP; p.N = K; p.NP = W.KP;
         p.A = W.g; p.a_bf16 = 1; p.lda = W.NP; p.W = W.WTp;
         p.out_f32 = dx; p.ldo = K;
+        p.drop = in_drop; p.seedword = seedword;        // d drop(x) / dx: the forward's input mask, index m*KP + k = this output's m*NP + n
         if ((rc = launch_rowgemm<EPI_PLAIN, false>(p, st, S_LINEAR_BWD_DX))) return rc;
     }
     if (dW || db) {
-        hipLaunchKernelGGL(cast_rows_kernel, dim3(grid_for((size_t)M * (W.KP / 4))), dim3(256), 0, st, x, W.xb, M, K, W.KP);
+        hipLaunchKernelGGL(cast_rows_kernel, dim3(grid_for((size_t)M * (W.KP / 4))), dim3(256), 0, st, x, W.xb, M, K, W.KP, in_drop, seedword);
         LAUNCH_CHECK("cast_rows_kernel");
         WgradJobs J; memset(&J, 0, sizeof(J));
         J.njobs = 1; J.MP = W.MP; J.M16 = W.M16; J.mchunk = W.mchunk;
@@ -1026,6 +1074,67 @@ extern "C" int mmt_linear_backward(const float* dy, const float* x, const float*
     return MMT_OK;
 }
 
+extern "C" int mmt_linear_backward(const float* dy, const float* x, const float* Wt, const float* y, const float* rowscale,
+                                   float* dx, float* dW, float* db,
+                                   void* workspace, size_t workspace_bytes, int M, int K, int N, int act, mmt_stream_t stream) {
+    return linear_backward_impl(dy, x, Wt, y, rowscale, dx, dW, db, workspace, workspace_bytes, M, K, N, act, 0.f, 0.f, 0, false, stream);
+}
+extern "C" int mmt_linear_dropout_backward(const float* dy, const float* x, const float* Wt, const float* y, const float* rowscale,
+                                           float* dx, float* dW, float* db,
+                                           void* workspace, size_t workspace_bytes, int M, int K, int N, int act,
+                                           float in_dropout_p, float out_dropout_p, uint64_t seed, int device_seeded, mmt_stream_t stream) {
+    return linear_backward_impl(dy, x, Wt, y, rowscale, dx, dW, db, workspace, workspace_bytes, M, K, N, act, in_dropout_p, out_dropout_p, seed,
+                                device_seeded != 0, stream);
+}
+
+// ------------------------------------------------------------------------------------ data movement between the kernels (glue.h)
+extern "C" int mmt_copy2d(const mmt_copy_seg* segs, int nsegs, mmt_stream_t stream) {
+    if (!segs || nsegs <= 0) return fail(MMT_EINVAL, "copy2d: no segments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int s0 = 0; s0 < nsegs; s0 += MMT_COPY_MAX_SEGS) {
+        CopySegs S; memset(&S, 0, sizeof(S));
+        S.n = std::min(MMT_COPY_MAX_SEGS, nsegs - s0);
+        size_t most = 0;
+        for (int i = 0; i < S.n; ++i) {
+            const mmt_copy_seg& a = segs[s0 + i];
+            CopySeg& g = S.s[i];
+            if (!a.dst || a.rows < 0 || a.cols < 0 || a.perm < 0 || a.perm > 2) return fail(MMT_EINVAL, "copy2d: bad segment %d", s0 + i);
+            if (a.perm && ((long)a.pB * a.pT != a.rows || a.pB <= 0 || a.pT <= 0)) return fail(MMT_EINVAL, "copy2d: segment %d: rows != B*T", s0 + i);
+            g.src = a.src; g.src2 = a.src2; g.dst = a.dst; g.rowscale = a.rowscale;
+            g.rows = a.rows; g.cols = a.cols; g.src_ld = a.src_ld; g.src2_ld = a.src2_ld; g.dst_ld = a.dst_ld;
+            g.perm = a.perm; g.pB = a.pB; g.pT = a.pT; g.accumulate = a.accumulate;
+            auto al = [](const void* q, int ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0; };
+            g.vec4 = (a.cols & 3) == 0 && al(a.dst, a.dst_ld) && (!a.src || al(a.src, a.src_ld)) && (!a.src2 || al(a.src2, a.src2_ld));
+            most = std::max(most, (size_t)a.rows * (g.vec4 ? a.cols / 4 : a.cols));
+        }
+        if (most == 0) continue;
+        hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(most), S.n), dim3(256), 0, st, S);
+        LAUNCH_CHECK("copy2d_kernel");
+    }
+    return MMT_OK;
+}
+extern "C" int mmt_softmax_mul_forward(const float* logits, const float* v, float* att, float* out, int M, int N, mmt_stream_t stream) {
+    if (!logits || !v || !att || !out) return fail(MMT_EINVAL, "null pointer argument");
+    if (M <= 0 || N <= 0) return fail(MMT_EINVAL, "bad shape M=%d N=%d", M, N);
+    hipLaunchKernelGGL(softmax_mul_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), logits, v, att, out, M, N);
+    LAUNCH_CHECK("softmax_mul_fwd_kernel");
+    return MMT_OK;
+}
+extern "C" int mmt_softmax_mul_backward(const float* dout, const float* att, const float* v, float* dlogits, float* dv, int M, int N,
+                                        mmt_stream_t stream) {
+    if (!dout || !att || !v || !dlogits || !dv) return fail(MMT_EINVAL, "null pointer argument");
+    if (M <= 0 || N <= 0) return fail(MMT_EINVAL, "bad shape M=%d N=%d", M, N);
+    hipLaunchKernelGGL(softmax_mul_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), dout, att, v, dlogits, dv, M, N);
+    LAUNCH_CHECK("softmax_mul_bwd_kernel");
+    return MMT_OK;
+}
+extern "C" int mmt_colsum(const float* x, float* out, int rows, int cols, int ld, mmt_stream_t stream) {
+    if (!x || !out) return fail(MMT_EINVAL, "null pointer argument");
+    if (rows <= 0 || cols <= 0 || ld < cols) return fail(MMT_EINVAL, "bad shape rows=%d cols=%d ld=%d", rows, cols, ld);
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, rows, cols, ld);
+    LAUNCH_CHECK("colsum_kernel");
+    return MMT_OK;
+}
 
 // ------------------------------------------------------------------------------------ LSTM scan
 struct LstmWs { unsigned* err; cl_u64* xb; bf16 *Wf, *Wb; size_t xb_bytes; int HP16, HPAD; size_t bytes; };

@@ -1,0 +1,98 @@
+// Data movement and the small element-wise steps between the GEMMs and the scans of the sequence models, so that a model's forward and
+// backward issue no library (ATen) kernel:
+//   * copy2d_kernel   — up to MMT_COPY_MAX_SEGS strided 2-D copies per launch: column concatenation and its split (the MFN's cStar
+//                       = [c_{t-1} of every modality ; c_t of every modality] and [h ; mem], transformer/MFT/multiTransformer.py:212-217,241-243),
+//                       the one-step time shift of c, batch-major <-> time-major row permutation ((B,T,d) <-> (T,B,d), :300), column slices
+//                       of weights (gamma fc1 = [attended part | memory part], :221-223), row broadcasts, sums of two sources, row scaling
+//                       by the window mask (:310), zero fill, accumulation into the destination;
+//   * softmax_mul     — attended = softmax(logits) * cStar over the feature axis and its backward (:218-219);
+//   * colsum          — column sums of a few rows (gradient of a row that was broadcast over the batch).
+// All HBM-bound one-pass kernels: 16-byte accesses when every pointer / stride of a segment allows, else 4-byte.
+#pragma once
+#include "common.h"
+
+#define MMT_COPY_MAX_SEGS 24
+// perm: 0 none; 1: the source is batch-major (row r = b*T + t), the destination time-major (row t*B + b); 2: the reverse.
+// rowscale (optional) is indexed by the BATCH-major row in both permuted modes, by the row otherwise.
+// src == nullptr: zeros.  src2 (optional): added to src.  src_ld / src2_ld == 0: one row broadcast over all rows.  accumulate: dst += value.
+struct CopySeg {
+    const float* src; const float* src2; float* dst; const float* rowscale;
+    int rows, cols, src_ld, src2_ld, dst_ld, perm, pB, pT, accumulate, vec4;
+};
+struct CopySegs { CopySeg s[MMT_COPY_MAX_SEGS]; int n; };
+
+__global__ __launch_bounds__(256) void copy2d_kernel(const CopySegs segs) {
+    const CopySeg& g = segs.s[blockIdx.y];
+    const int cpr = g.vec4 ? (g.cols >> 2) : g.cols;                   // work items per row
+    const size_t total = (size_t)g.rows * cpr;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int r = (int)(idx / cpr), c = (int)(idx - (size_t)r * cpr) * (g.vec4 ? 4 : 1);
+        int rd = r, rb = r;                                             // destination row, batch-major row (for rowscale)
+        if (g.perm == 1) { const int b = r / g.pT, t = r - b * g.pT; rd = t * g.pB + b; }
+        else if (g.perm == 2) { const int t = r / g.pB, b = r - t * g.pB; rd = b * g.pT + t; rb = rd; }
+        const float rs = g.rowscale ? g.rowscale[rb] : 1.f;
+        float* d = g.dst + (size_t)rd * g.dst_ld + c;
+        if (g.vec4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (g.src) v = *reinterpret_cast<const f32x4*>(g.src + (size_t)r * g.src_ld + c);
+            if (g.src2) v += *reinterpret_cast<const f32x4*>(g.src2 + (size_t)r * g.src2_ld + c);
+            v *= rs;
+            if (g.accumulate) v += *reinterpret_cast<const f32x4*>(d);
+            *reinterpret_cast<f32x4*>(d) = v;
+        } else {
+            float v = g.src ? g.src[(size_t)r * g.src_ld + c] : 0.f;
+            if (g.src2) v += g.src2[(size_t)r * g.src2_ld + c];
+            v *= rs;
+            if (g.accumulate) v += *d;
+            *d = v;
+        }
+    }
+}
+
+// attended[m][n] = softmax_n(logits[m][:])[n] * v[m][n]; att is kept for the backward.  One wave per row, 4 rows per workgroup.
+__global__ __launch_bounds__(256) void softmax_mul_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ v,
+                                                              float* __restrict__ att, float* __restrict__ out, int M, int N) {
+    const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* lr = logits + (size_t)m * N;
+    float mx = -INFINITY;
+    for (int n = lane; n < N; n += 64) mx = fmaxf(mx, lr[n]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int n = lane; n < N; n += 64) sum += __expf(lr[n] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+    for (int n = lane; n < N; n += 64) {
+        const float a = __expf(lr[n] - mx) * inv;
+        att[(size_t)m * N + n] = a;
+        out[(size_t)m * N + n] = a * v[(size_t)m * N + n];
+    }
+}
+// g = dout * v;  dlogits = att * (g - sum_n g att);  dv = dout * att
+__global__ __launch_bounds__(256) void softmax_mul_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ att,
+                                                              const float* __restrict__ v, float* __restrict__ dlogits,
+                                                              float* __restrict__ dv, int M, int N) {
+    const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const size_t o0 = (size_t)m * N;
+    float dot = 0.f;
+    for (int n = lane; n < N; n += 64) dot += dout[o0 + n] * v[o0 + n] * att[o0 + n];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    for (int n = lane; n < N; n += 64) {
+        const float a = att[o0 + n], d = dout[o0 + n];
+        dlogits[o0 + n] = a * (d * v[o0 + n] - dot);
+        dv[o0 + n] = d * a;
+    }
+}
+
+// out[c] = sum_r x[r][c] in a fixed order (rows is small: a batch)
+__global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int cols, int ld) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += x[(size_t)r * ld + c];
+    out[c] = s;
+}

@@ -307,39 +307,39 @@ class MFN(nn.Module):
         self.device = _hip_device(device)
         self.to(self.device)
 
+    def _gate_params(self):
+        out = []
+        for l in (self.att1_fc1, self.att1_fc2, self.att2_fc1, self.att2_fc2, self.gamma1_fc1, self.gamma1_fc2,
+                  self.gamma2_fc1, self.gamma2_fc2, self.out_fc1, self.out_fc2):
+            out += [l.weight, l.bias]
+        return out
+
     def forward(self, inputs):
+        return self._gate(inputs, None)
+
+    def _gate(self, inputs, mask):
+        """inputs: {mod: (T,B,d)} -> (B,T,output_dim).  ``mask`` (B,T,1) or None: multiplied onto the output while it is brought
+        back to batch-major (MultiTransformer's ``* mask.float()``, :310, in the same pass)."""
         pg = self.gamma1_dropout.p if self.training else 0.0        # gamma dropout runs inside the memory scan
         if self.training and self.gamma2_dropout.p != self.gamma1_dropout.p:
             raise NotImplementedError("MFN: gamma1_dropout and gamma2_dropout must share one probability")
-        seed = _lib.next_dropout_seed(self.device, 2, holder=self) if pg > 0.0 else 0
-        hs, c_prev, c_new = [], [], []
+        if self.training and (self.att1_dropout.p or self.att2_dropout.p):
+            raise NotImplementedError("MFN: att1_dropout / att2_dropout are 0 in the reference (:161,165); other values are not implemented")
+        po = self.out_dropout.p if self.training else 0.0           # out_dropout rides in the read-out kernel's epilogue
+        seed_g = _lib.next_dropout_seed(self.device, 2, holder=self) if pg > 0.0 else 0
+        seed_o = _lib.next_dropout_seed(self.device, 4, holder=self) if po > 0.0 else 0
+        hs, cs = [], []
         main, streams = _MOD_STREAMS.begin(self.device, len(self.mods))
         for mod, st in zip(self.mods, streams):
             with torch.cuda.stream(st):
                 cell = self.lstm[mod]
-                x = inputs[mod]                                       # (T,B,d), possibly a permuted view
-                gx = F_hip.linear(x, cell.weight_ih, cell.bias_ih + cell.bias_hh)
+                gx = F_hip.linear(inputs[mod], cell.weight_ih, F_hip.add2(cell.bias_ih, cell.bias_hh))     # (T,B,4H)
                 h_all, c_all = F_hip.lstm_scan(gx, cell.weight_hh)
                 hs.append(h_all)
-                c_new.append(c_all)
-                c_prev.append(torch.cat([torch.zeros_like(c_all[:1]), c_all[:-1]], dim=0))
-        _MOD_STREAMS.end(main, streams, hs + c_new + c_prev)
-        c_star = torch.cat(c_prev + c_new, dim=-1)                    # (T,B,2*sumH)   :215-217
-        A = c_star.shape[-1]
-        att = torch.softmax(F_hip.linear(F_hip.linear(c_star, self.att1_fc1.weight, self.att1_fc1.bias, act=1),
-                                         self.att1_fc2.weight, self.att1_fc2.bias), dim=-1)
-        attended = att * c_star
-        c_hat = F_hip.linear(F_hip.linear(attended, self.att2_fc1.weight, self.att2_fc1.bias, act=1),
-                             self.att2_fc2.weight, self.att2_fc2.bias, act=2)
-        w1 = torch.cat([self.gamma1_fc1.weight, self.gamma2_fc1.weight], dim=0)          # (128, A+mem)
-        apre = F_hip.linear(attended, w1[:, :A], torch.cat([self.gamma1_fc1.bias, self.gamma2_fc1.bias]))
-        mem_all = F_hip.mfn_mem_scan(apre, c_hat, w1[:, A:],
-                                     torch.stack([self.gamma1_fc2.weight, self.gamma2_fc2.weight]),
-                                     torch.stack([self.gamma1_fc2.bias, self.gamma2_fc2.bias]), dropout_p=pg, seed=seed)
-        last = torch.cat(hs + [mem_all], dim=-1)
-        hid = self.out_dropout(F_hip.linear(last, self.out_fc1.weight, self.out_fc1.bias, act=1))   # nn.Dropout: identity in eval
-        out = F_hip.linear(hid, self.out_fc2.weight, self.out_fc2.bias)
-        return out.permute(1, 0, 2)
+                cs.append(c_all)
+        _MOD_STREAMS.end(main, streams, hs + cs)
+        out = F_hip.mfn_gate(hs, cs, self._gate_params(), pg, seed_g, po, seed_o)          # (T,B,output_dim)
+        return F_hip.batch_major(out, mask)
 
 
 class MultiTransformer(nn.Module):
@@ -376,9 +376,9 @@ class MultiTransformer(nn.Module):
             with torch.cuda.stream(st):
                 e = F_hip.linear(inputs[mod], self.embed[mod].weight, self.embed[mod].bias)
                 e = self.transformer[mod](e, mask)
-                gate_in[mod] = e.permute(1, 0, 2)
+                gate_in[mod] = F_hip.time_major(e)                    # (T,B,d): the reference's permute(1,0,2), :300
         _MOD_STREAMS.end(main, streams, list(gate_in.values()))
-        return self.mfn(gate_in) * mask.float()
+        return self.mfn._gate(gate_in, mask)                         # ... * mask (:310) in the gate's last pass
 
 
 class _DecoderMixin:
@@ -392,16 +392,13 @@ class _DecoderMixin:
         B, T, d = enc.shape
         if self.decoder.num_layers != 1:
             raise NotImplementedError("only the reference's single-layer decoder is supported")
-        W_ih, W_hh = self.decoder.weight_ih_l0, self.decoder.weight_hh_l0
-        bias = self.decoder.bias_ih_l0 + self.decoder.bias_hh_l0
-        gx = F_hip.linear(enc.transpose(0, 1), W_ih[:, d:], bias)                           # (T,B,4d)
-        first = F_hip.linear(self.dec_h0[0], W_hh)                                          # (1,4d): h0 W_hh^T
-        gx = torch.cat([gx[:1] + first.unsqueeze(0), gx[1:]], dim=0)
-        c0 = self.dec_c0[0].expand(B, d)
-        h_all, _ = F_hip.lstm_scan(gx, W_ih[:, :d] + W_hh, None, c0)
-        o = h_all.transpose(0, 1)                                                           # (B,T,d)
-        hid = F_hip.linear(o, self.out[0].weight, self.out[0].bias, act=1)
-        return F_hip.linear(hid, self.out[2].weight, self.out[2].bias, rowscale=mask.float().reshape(-1))
+        Wx, W_rec, Whh, bias = F_hip.decoder_pack(self.decoder.weight_ih_l0, self.decoder.weight_hh_l0,
+                                                  self.decoder.bias_ih_l0, self.decoder.bias_hh_l0)
+        gx = F_hip.linear(F_hip.time_major(enc), Wx, bias)                                  # (T,B,4d)
+        gx = F_hip.add_row0(gx, F_hip.linear(self.dec_h0, Whh))                             # step 0 sees h0 W_hh^T (in place, no concat)
+        h_all, _ = F_hip.lstm_scan(gx, W_rec, None, F_hip.broadcast_rows(self.dec_c0, B))
+        hid = F_hip.linear(h_all, self.out[0].weight, self.out[0].bias, act=1)              # rows stay time-major ...
+        return F_hip.batch_major(F_hip.linear(hid, self.out[2].weight, self.out[2].bias), mask)   # ... until the mask pass
 
 
 class UniTransformer(nn.Module, _DecoderMixin):
@@ -462,6 +459,7 @@ class NLPTransformer(nn.Module, _DecoderMixin):
         self.to(self.device)
 
     def forward(self, inputs, mask, lengths, tgt_init=0.5, target=None):
-        x = self.embed[0](inputs)                       # nn.Dropout: identity in eval mode (train: torch's generator)
-        e = F_hip.linear(x, self.embed[1].weight, self.embed[1].bias, act=1)
+        p_in = float(self.embed[0].p) if self.training else 0.0      # Dropout(0.1) on the input rides in the embed kernel's A-tile staging
+        seed = _lib.next_dropout_seed(inputs.device, 5, holder=self) if p_in > 0.0 else 0
+        e = F_hip.linear(inputs, self.embed[1].weight, self.embed[1].bias, act=1, in_dropout=p_in, seed=seed)
         return self._decode(self.encoder(e, mask), mask)

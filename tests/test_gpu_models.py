@@ -334,3 +334,134 @@ def test_evaluate_loop_matches_per_sequence_oracle(dev):
     for i in (1, 2):
         L = lengths[i]
         assert rel_l2(got[i, :L, 0], unpadded[i]) > 0.2, "padding windows are keys of the shorter sequences in the reference"
+
+
+def test_glue_ops_match_torch(dev):
+    """The data-movement ops that replace torch.cat / permute / slicing / broadcasting around the scans (csrc/glue.h, mmt_copy2d): forward
+    values equal torch's own ops exactly (they only move fp32 numbers; sums of two terms are commutative), gradients to round-off."""
+    F = mta().functional
+    B, T, d = 3, 7, 20
+    x = R.gen_normal("glue:x", (B, T, d), 3).to(dev)
+    m = R.prefix_mask([7, 4, 1], T).to(dev)
+    g = R.gen_normal("glue:g", (B, T, d), 3).to(dev)
+
+    def both(fn_hip, fn_ref, *leaves):
+        a = [t.clone().requires_grad_() for t in leaves]
+        b = [t.clone().requires_grad_() for t in leaves]
+        ya, yb = fn_hip(*a), fn_ref(*b)
+        assert ya.shape == yb.shape and torch.equal(ya, yb)
+        go = R.gen_normal("glue:go%d" % ya.numel(), tuple(ya.shape), 3).to(dev)
+        ya.backward(go)
+        yb.backward(go)
+        for p, q in zip(a, b):
+            qg = q.grad if q.grad is not None else torch.zeros_like(q)      # (torch leaves the gradient of an unused leaf undefined)
+            assert torch.allclose(p.grad, qg, rtol=2e-6, atol=1e-6)         # (a broadcast row's gradient is a sum over the batch: order may differ)
+
+    both(F.time_major, lambda t: t.permute(1, 0, 2).contiguous(), x)
+    xt = x.permute(1, 0, 2).contiguous()
+    both(lambda t: F.batch_major(t, m), lambda t: t.permute(1, 0, 2) * m, xt)
+    both(lambda t: F.batch_major(t), lambda t: t.permute(1, 0, 2).contiguous(), xt)
+    W = R.gen_normal("glue:W", (12, 44), 3).to(dev)
+    both(F.add2, lambda a, b: a + b, W, W.flip(0).contiguous())
+    Wi, Wh = R.gen_normal("glue:Wi", (16, 8), 3).to(dev), R.gen_normal("glue:Wh", (16, 4), 3).to(dev)
+    bi, bh = R.gen_normal("glue:bi", (16,), 3).to(dev), R.gen_normal("glue:bh", (16,), 3).to(dev)
+    for k in range(4):          # the four outputs of the decoder's operand pack, each against the slicing / sums it replaces
+        both(lambda a, b, c, e, k=k: F.decoder_pack(a, b, c, e)[k],
+             lambda a, b, c, e, k=k: (a[:, 4:].contiguous(), a[:, :4] + b, b * 1.0, c + e)[k], Wi, Wh, bi, bh)
+    v = R.gen_normal("glue:v", (44,), 3).to(dev)
+    both(F.add2, lambda a, b: a + b, v, v.flip(0).contiguous())
+    row = R.gen_normal("glue:row", (1, 1, d), 3).to(dev)
+    both(lambda t, r: F.add_row0(t * 1.0, r), lambda t, r: torch.cat([t[:1] + r.reshape(1, 1, -1), t[1:]], 0), xt, row)
+    both(lambda r: F.broadcast_rows(r, 5), lambda r: r.reshape(1, -1).expand(5, d).contiguous(), row)
+    parts = [R.gen_normal("glue:p%d" % i, (T, B, w), 3).to(dev) for i, w in enumerate((8, 3, 20))]
+    both(lambda *t: F.cat_cols(t), lambda *t: torch.cat(t, dim=-1), *parts)
+
+
+@pytest.mark.parametrize("in_p,out_p", [(0.1, 0.0), (0.0, 0.5), (0.25, 0.5)])
+def test_linear_fused_dropout_replay(dev, in_p, out_p):
+    """Dropout fused into the affine map — on the input (NLPTransformer's Dropout -> Linear -> ReLU embed, transformer/SFT/multiTransformer.py:431-433)
+    and behind the ReLU (MFN's out_dropout, transformer/MFT/multiTransformer.py:244-245): the masks the kernel used are rebuilt with
+    mmt_debug_dropout_mask (streams 2000 / 2001) and replayed through plain fp64 torch, forward and all three gradients."""
+    F = mta().functional
+    M, K, N, seed = 70, 300, 96, 99
+    KP, NP = -(-K // 64) * 64, -(-N // 64) * 64
+    x = R.gen_normal("ldrop:x", (M, K), 7)
+    W = R.gen_normal("ldrop:W", (N, K), 7) * 0.08
+    b = R.gen_normal("ldrop:b", (N,), 7) * 0.1
+    g = R.gen_normal("ldrop:g", (M, N), 7)
+    xs, Ws, bs = (t.to(dev).requires_grad_() for t in (x, W, b))
+    y = F.linear(xs, Ws, bs, act=1, in_dropout=in_p, out_dropout=out_p, seed=seed)
+    y.backward(g.to(dev))
+    min_ = torch.ones(M, K, dtype=torch.float64)
+    mout = torch.ones(M, N, dtype=torch.float64)
+    if in_p > 0:
+        kk, sc = F.dropout_mask(in_p, seed, 2000, M * KP, dev)
+        min_ = (kk.reshape(M, KP)[:, :K].double() * sc).cpu()
+        assert abs(float(1 - kk.float().mean()) - in_p) < 0.02
+    if out_p > 0:
+        kk, sc = F.dropout_mask(out_p, seed, 2001, M * NP, dev)
+        mout = (kk.reshape(M, NP)[:, :N].double() * sc).cpu()
+    xd, Wd, bd = (t.double().requires_grad_() for t in (x, W, b))
+    ref = torch.relu((xd * min_) @ Wd.t() + bd) * mout
+    ref.backward(g.double())
+    tag = "linear drop in %.2f out %.2f" % (in_p, out_p)
+    assert _report(tag + " y", y.detach().cpu(), ref.detach()) < OUT_RTOL
+    assert _report(tag + " dx", xs.grad.cpu(), xd.grad) < RELU_GRAD_RTOL
+    assert _report(tag + " dW", Ws.grad.cpu(), Wd.grad) < RELU_GRAD_RTOL
+    assert _report(tag + " db", bs.grad.cpu(), bd.grad) < RELU_GRAD_RTOL
+    y2 = F.linear(xs.detach(), Ws.detach(), bs.detach(), act=1, in_dropout=in_p, out_dropout=out_p, seed=seed + 1)
+    assert float((y2 - y.detach()).abs().max()) > 1e-3            # another seed, another mask
+
+
+def _device_kernel_names(step):
+    """names of the device kernels one call of `step` launches (torch.profiler); None if the profiler reports no device activity"""
+    from torch.profiler import profile, ProfilerActivity
+    from torch.autograd import DeviceType
+    step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        step()
+        torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if e.device_type == DeviceType.CUDA]
+    return names or None
+
+
+def _library_kernels(names):
+    """kernels that are not ours: ATen element-wise / reduction / copy / cat kernels, rocBLAS / hipBLASLt / MIOpen GEMMs"""
+    bad = ("at::", "at_cuda", "elementwise", "Cijk_", "rocblas", "hipblas", "miopen", "MIOpen", "CatArray", "reduce_kernel", "vectorized_")
+    return sorted(set(n for n in names if any(b in n for b in bad)))
+
+
+@pytest.mark.parametrize("which", ["mft", "sft"])
+def test_train_step_runs_no_library_kernel(dev, which):
+    """One train-mode forward + loss + backward of the whole MFT / SFT sequence model launches hand-written HIP kernels only — no ATen
+    element-wise, concatenation or copy kernel, no library GEMM (the MFN gate's softmax(att1) * cStar, the shift of c, the concatenations
+    and the output dropout, transformer/MFT/multiTransformer.py:210-219,238-246; the SFT embed dropout and decoder glue,
+    transformer/SFT/multiTransformer.py:431-433,461-483, used to be torch ops)."""
+    MT = mta().multiTransformer
+    F = mta().functional
+    B, T = 4, 40
+    lengths = [40, 33, 20, 5]
+    mask = R.prefix_mask(lengths, T).to(dev)
+    tgt = (R.gen_uniform("nolib:t", (B, T, 1), 3) * R.prefix_mask(lengths, T)).to(dev)
+    if which == "mft":
+        model = MT.MultiTransformer(R.MODS_AVL, R.EMBED_AVL, device=dev).train()
+        x = {m: R.gen_normal("nolib:" + m, (B, T, R.EMBED_AVL[m]), 3).to(dev) for m in R.MODS_AVL}
+    else:
+        model = MT.NLPTransformer(512, embed_dim=128, h=8, device=dev).train()
+        x = torch.tanh(R.gen_normal("nolib:x", (B, T, 512), 3)).to(dev)
+    params = list(model.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        F.mse_sum_loss_backward(model(x, mask, lengths), tgt, sum(lengths))
+
+    names = _device_kernel_names(step)
+    if names is None:
+        pytest.skip("torch.profiler reports no device kernels on this box")
+    ours = [n for n in names if "kernel" in n]
+    assert len(ours) > 20, names[:10]
+    assert _library_kernels(names) == [], "library kernels in a %s train step: %s" % (which, _library_kernels(names))
+    for p in params:
+        assert p.grad is None or torch.isfinite(p.grad).all()
