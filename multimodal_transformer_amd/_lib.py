@@ -313,6 +313,8 @@ def next_dropout_seed(device, site, holder=None):
     kernels read and advance, so every REPLAY draws new masks.  It is created at the module's first eager train-mode call (seeded
     from the generator as above); capturing a module that never ran eagerly raises (a warm-up step always precedes a capture)."""
     capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    if os.environ.get("MMT_DEVICE_SEED") == "0":         # developer switch: by-value seeds even under capture (frozen at capture, as in round 2)
+        holder = None
     if holder is not None:
         ds = holder.__dict__.get("_dev_seed")
         if ds is None or ds.state.device != device:

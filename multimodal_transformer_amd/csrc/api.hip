@@ -186,7 +186,7 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base, bool train = t
     Carver c(base);
     const LayerLayout& L = D.L;
     const size_t M = D.M, MP = D.MP, BH = (size_t)D.B * D.h;
-    W.seedword = c.take<uint64_t>(1);
+    W.seedword = c.take<uint64_t>(MMT_SEED_BLOCK_WORDS);
     W.wprep = c.take<bf16>(L.pstride() * (size_t)(D.N > 0 ? D.N : 1));
     W.bprep = c.take<float>(L.qstride() * (size_t)(D.N > 0 ? D.N : 1));
     W.statsf = c.take<float>(2 * M);
@@ -292,10 +292,17 @@ static DropCfg no_drop() { return make_drop(0.f, 0, 0); }
 // Dropout configuration of one stream: keys mixed on the host from a by-value seed, or — device-resident seed (`devseed`) — the stream id
 // in s0 for the kernels to resolve against the workspace's seed word (common.h drop_resolve)
 #define MMT_ATTN_DROP_BITS 12         // resolution of the attention-probability dropout (common.h make_drop)
-static DropCfg stream_drop(float p, uint64_t seed, uint32_t stream, bool devseed, int bits = 16) {
+// `first`: the stream whose keys sit in slot 0 of the workspace's seed block (seed_advance_kernel)
+static DropCfg stream_drop(float p, uint64_t seed, uint32_t stream, bool devseed, int bits = 16, uint32_t first = 0) {
     DropCfg c = make_drop(p, seed, stream, bits);
-    if (devseed) { c.s0 = stream; c.s1 = 0; }
+    if (devseed) { c.s0 = stream - first; c.s1 = 0; }
     return c;
+}
+static int launch_seed_advance(uint64_t* state, uint64_t* block, uint32_t first, int n, hipStream_t st) {
+    if (n + 1 > MMT_SEED_BLOCK_WORDS) return fail(MMT_EUNSUPPORTED, "%d dropout streams do not fit the seed block", n);
+    hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(128), 0, st, state, block, first, n);
+    LAUNCH_CHECK("seed_advance_kernel");
+    return MMT_OK;
 }
 
 // Attention-probability dropout of `nlayers` layers: ONE launch draws every decision (stream 4l+0 of layer l) into the lane-mask
@@ -452,10 +459,7 @@ static int encoder_forward_impl(const float* x, const float* mask, const float* 
     const LayerLayout& L = D.L;
     const bool devseed = seed_state != nullptr && dropout_p > 0.f;
     const uint64_t* seedword = devseed ? W.seedword : nullptr;
-    if (devseed) {
-        hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, st, seed_state, W.seedword);
-        LAUNCH_CHECK("seed_advance_kernel");
-    }
+    if (devseed && (rc = launch_seed_advance(seed_state, W.seedword, 0, 4 * D.N + 4, st))) return rc;
     auto mkdrop = [&](int stream_id) { return stream_drop(dropout_p, seed, (uint32_t)stream_id, devseed, (stream_id & 3) == 0 ? MMT_ATTN_DROP_BITS : 16); };
 
     if (D.N > 0 && dropout_p > 0.f) {
@@ -959,7 +963,7 @@ __global__ void cast_rows_kernel(const float* __restrict__ src, bf16* __restrict
 struct LinWs { uint64_t* seedword; bf16 *Wp, *WTp, *g, *xb; float *bp, *sW, *sb; int KP, NP, MP, M16, nsplit, mchunk; size_t bytes; };
 static void carve_linear(LinWs& W, int M, int K, int N, void* base) {
     Carver c(base);
-    W.seedword = c.take<uint64_t>(1);
+    W.seedword = c.take<uint64_t>(MMT_SEED_BLOCK_WORDS);
     W.KP = round_up(K, 64); W.NP = round_up(N, 64); W.MP = round_up(M, 64); W.M16 = round_up(M, 16);
     const int tiles = (W.NP / 64) * (W.KP / 64);
     int s = (512 + tiles - 1) / tiles; if (s < 1) s = 1; if (s > 32) s = 32;
@@ -1010,12 +1014,11 @@ static int linear_forward_impl(const float* x, const float* Wt, const float* b, 
     p.out_f32 = y; p.ldo = N;
     const bool devseed = seed_state != nullptr && (in_p > 0.f || out_p > 0.f);
     if (devseed) {
-        hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, st, seed_state, W.seedword);
-        LAUNCH_CHECK("seed_advance_kernel");
+        if ((rc = launch_seed_advance(seed_state, W.seedword, MMT_LINEAR_IN_STREAM, 2, st))) return rc;
         p.seedword = W.seedword;
     }
-    p.a_drop = stream_drop(in_p, seed, MMT_LINEAR_IN_STREAM, devseed);        // x -> drop(x) as the A tile is staged (index m*KP + k)
-    p.drop = stream_drop(out_p, seed, MMT_LINEAR_OUT_STREAM, devseed);        // behind the activation (index m*NP + n)
+    p.a_drop = stream_drop(in_p, seed, MMT_LINEAR_IN_STREAM, devseed, 16, MMT_LINEAR_IN_STREAM);     // x -> drop(x) as the A tile is staged (index m*KP + k)
+    p.drop = stream_drop(out_p, seed, MMT_LINEAR_OUT_STREAM, devseed, 16, MMT_LINEAR_IN_STREAM);     // behind the activation (index m*NP + n)
     return launch_rowgemm<EPI_PLAIN, false>(p, st, S_LINEAR_FWD);
 }
 extern "C" int mmt_linear_forward(const float* x, const float* Wt, const float* b, const float* rowscale, float* y,
@@ -1041,7 +1044,7 @@ static int linear_backward_impl(const float* dy, const float* x, const float* Wt
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool devseed = devseed_in && (in_p > 0.f || out_p > 0.f);
     const uint64_t* seedword = devseed ? W.seedword : nullptr;              // left there by the forward
-    const DropCfg in_drop = stream_drop(in_p, seed, MMT_LINEAR_IN_STREAM, devseed);
+    const DropCfg in_drop = stream_drop(in_p, seed, MMT_LINEAR_IN_STREAM, devseed, 16, MMT_LINEAR_IN_STREAM);
     hipLaunchKernelGGL(grad_prep_kernel, dim3(grid_for((size_t)M * (W.NP / 4))), dim3(256), 0, st, dy, y, rowscale, act, W.g, M, N, W.NP,
                        make_drop(out_p, 0, 0).scale);
     LAUNCH_CHECK("grad_prep_kernel");
@@ -1367,7 +1370,7 @@ extern "C" int mmt_convpool_backward(const float* x, const float* dout, const in
 struct MfnWs { uint64_t* seedword; bf16 *WmF, *W2F, *WmB, *W2B; size_t bytes; };
 static void carve_mfn(MfnWs& W, void* base) {
     Carver c(base);
-    W.seedword = c.take<uint64_t>(1);
+    W.seedword = c.take<uint64_t>(MMT_SEED_BLOCK_WORDS);
     W.WmF = c.take<bf16>(MFN_U * MFN_MD); W.W2F = c.take<bf16>(2 * MFN_MD * MFN_HG);
     W.WmB = c.take<bf16>(MFN_MD * MFN_U); W.W2B = c.take<bf16>(MFN_U * MFN_MD);
     W.bytes = c.off;
@@ -1393,13 +1396,11 @@ static int mfn_mem_scan_forward_impl(const float* apre, const float* chat, const
     hipLaunchKernelGGL(mfn_prep_kernel, dim3(64), dim3(256), 0, st, Wm, W2, W.WmF, W.W2F, W.WmB, W.W2B);
     LAUNCH_CHECK("mfn_prep_kernel");
     const bool devseed = seed_state != nullptr && dropout_p > 0.f;
-    if (devseed) {      // the gamma mask is not regenerated by the backward (u_all keeps the dropped values): no copy of the seed is needed after this launch
-        hipLaunchKernelGGL(seed_advance_kernel, dim3(1), dim3(1), 0, st, seed_state, W.seedword);
-        LAUNCH_CHECK("seed_advance_kernel");
-    }
+    // (the gamma mask is not regenerated by the backward — u_all keeps the dropped values — so nothing reads the block after this launch)
+    if (devseed && (rc = launch_seed_advance(seed_state, W.seedword, 1000, 1, st))) return rc;
     ProfScope prof(S_MEM_FWD, st);
     hipLaunchKernelGGL(mfn_mem_scan_fwd_kernel, dim3((B + scan_bt(B) - 1) / scan_bt(B)), dim3(512), 0, st, apre, chat, W.WmF, W.W2F, b2, mem_all, u_all, g_all, T, B, scan_bt(B),
-                       stream_drop(dropout_p, seed, 1000, devseed), devseed ? W.seedword : nullptr);
+                       stream_drop(dropout_p, seed, 1000, devseed, 16, 1000), devseed ? W.seedword : nullptr);
     LAUNCH_CHECK("mfn_mem_scan_fwd_kernel");
     return MMT_OK;
 }

@@ -148,23 +148,28 @@ __host__ __device__ inline uint64_t splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 // Device-resident seeds.  A step that is replayed from a hipGraph cannot take its seed by value (it would be frozen at capture): the
-// forward's first kernel (seed_advance_kernel) copies the caller's 64-bit seed state into the workspace's seed word and advances the
-// state, and every kernel of that forward AND of its backward derives its stream keys from the seed word.  Such a kernel receives a
-// DropCfg whose s0 holds the STREAM ID (s1 = 0) next to the pointer; drop_resolve() turns it into the same keys make_drop() gives on
-// the host for (seed, stream), so mmt_debug_dropout_mask(seed value, stream) replays a device-seeded mask too.
-__device__ __forceinline__ DropCfg drop_resolve(DropCfg c, const uint64_t* __restrict__ seedword) {
-    if (seedword && c.thr16) {
-        const uint64_t k = splitmix64(splitmix64(*seedword) + 0x100000001B3ull * (uint64_t)c.s0);
+// forward's first kernel (seed_advance_kernel) copies the caller's 64-bit seed state into the workspace's seed block, derives the keys
+// of every dropout stream the call uses into the same block and advances the state; every kernel of that forward AND of its backward
+// then fetches its stream's keys from the block (one 8-byte scalar load).  Such a kernel receives a DropCfg whose s0 holds the SLOT of
+// its stream in the block (s1 = 0) next to the block's pointer; the keys are those make_drop() gives on the host for (seed, stream), so
+// mmt_debug_dropout_mask(seed value, stream) replays a device-seeded mask too.
+//   block[0] = the seed of this forward;  block[1 + i] = (s0 | s1 << 32) of stream first_stream + i
+#define MMT_SEED_BLOCK_WORDS 80                 // uint64 words reserved in a workspace: 1 + up to 4 * 16 + 4 encoder streams
+__device__ __forceinline__ DropCfg drop_resolve(DropCfg c, const uint64_t* __restrict__ seedblock) {
+    if (seedblock && c.thr16) {
+        const uint64_t k = seedblock[1 + c.s0];
         c.s0 = (uint32_t)k;
         c.s1 = (uint32_t)(k >> 32);
     }
     return c;
 }
-// state[0]: the seed the NEXT train-mode forward uses.  One thread: seed word <- state, state <- splitmix64(state).
-__global__ void seed_advance_kernel(uint64_t* __restrict__ state, uint64_t* __restrict__ seedword) {
+// state[0]: the seed the NEXT train-mode forward uses.  seed block <- state and the stream keys, state <- splitmix64(state).
+__global__ void seed_advance_kernel(uint64_t* __restrict__ state, uint64_t* __restrict__ seedblock, uint32_t first_stream, int nstreams) {
     const uint64_t s = state[0];
-    seedword[0] = s;
-    state[0] = splitmix64(s);
+    const int i = threadIdx.x;
+    if (i < nstreams) seedblock[1 + i] = splitmix64(splitmix64(s) + 0x100000001B3ull * (uint64_t)(first_stream + i));
+    __syncthreads();                            // every thread has read the state
+    if (i == 0) { seedblock[0] = s; state[0] = splitmix64(s); }
 }
 // `bits`: resolution of the drop probability, P(drop) = round(p * 2^bits) / 2^bits.  16 for the streams that compare a 16-bit hash half
 // with the threshold; 12 for the attention-probability stream, whose bit-parallel generator (attn_mask.h) spends one hash word per

@@ -92,7 +92,7 @@ struct RowGemmParams {
     DropCfg next_drop; int next_lda;       // KEEP_AS: the next stage's A tile = bf16(drop(out)) is left in As with this row stride
     // ---- K-chunked A staging (bf16 A from global): only `kchunk` (a power of two >= 64) columns of the A tile are in LDS at a time
     int kchunk;                            // 0: the whole K
-    // ---- device-resident dropout seed (common.h drop_resolve): non-null = the DropCfg fields above carry stream ids, not keys
+    // ---- device-resident dropout seed (common.h drop_resolve): non-null = the DropCfg fields above carry stream slots, not keys
     const uint64_t* seedword;
 };
 
@@ -142,8 +142,18 @@ __device__ __forceinline__ ColPos col_pos(int n, int HD, int DKP) {
 // WIDE: the d_model > 128 variant of a LayerNorm-backward stage — K-chunked A staging (RowGemmParams::kchunk) and column sums without the
 // second fp32 tile (RowGemmParams::no_gs, which the host sets to match).  Its own instantiation, so that the d_model <= 128 kernels
 // carry neither the extra barriers nor the registers of the batched re-reads.
+// The stage's dropout streams with their keys resolved (device-resident seed: fetched from the workspace's seed block, common.h).  The
+// kernels resolve the keys of ALL their stages at entry, so the scalar loads run behind the first stage's staging instead of in front
+// of each stage's first masked element.
+struct StageDrops { DropCfg a, e, n; };
+__device__ __forceinline__ StageDrops stage_drops(const RowGemmParams& p) {
+    StageDrops d;
+    d.a = drop_resolve(p.a_drop, p.seedword); d.e = drop_resolve(p.drop, p.seedword); d.n = drop_resolve(p.next_drop, p.seedword);
+    return d;
+}
+
 template <int EPI, bool LNPRO, int ASRC, int KEEP, bool WIDE = false>
-__device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowSmem& sm) {
+__device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowSmem& sm, const StageDrops& sd) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int KP = p.KP, NP = p.NP, K = p.K, M = p.M;
     // K-chunked staging: kc columns of the A tile in LDS at a time (kc == KP: all of it, the usual case)
@@ -157,8 +167,6 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     constexpr int ROWS = MMT_ROWS, TPR = MMT_RTPR, MT = MMT_ROWS / 16;
     const int m0 = blockIdx.x * ROWS;
     const int l15 = lane & 15, lq = lane >> 4;
-    const DropCfg a_drop = drop_resolve(p.a_drop, p.seedword), e_drop = drop_resolve(p.drop, p.seedword),
-                  next_drop = drop_resolve(p.next_drop, p.seedword);      // wave-uniform: scalar registers
     PHASE_DECL
 
     // W fragments (straight from L2, ~1k cycles away) travel through a ring of PFD k-blocks per wave.  The first PFD blocks of the
@@ -241,6 +249,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         }
     } else if (ASRC == ASRC_X) {
         // fp32 tile kept by the previous stage -> bf16 (optionally through the dropout mask of index m*KP + k)
+        const DropCfg& a_drop = sd.a;
         for (int row = tid >> 4; row < ROWS; row += MMT_RTHREADS / 16)
         for (int c = (tid & 15) * 4; c < KP; c += 64) {
             const int m = m0 + row;
@@ -263,6 +272,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         stage_a16(0);
     } else {
         const float* A = static_cast<const float*>(p.A);
+        const DropCfg& a_drop = sd.a;
         for (int row = tid >> 4; row < ROWS; row += MMT_RTHREADS / 16)
         for (int c = (tid & 15) * 4; c < KP; c += 64) {
             const int m = m0 + row;
@@ -357,6 +367,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             // (non-restrict) output pointers would otherwise fence the later tasks' loads and serialise 4 L2 round trips.
             const int cg = tid & 31, n = n0 + cg * 4, rbase = tid >> 5;
             const bool col_ok = n < NP;
+            const DropCfg& e_drop = sd.e;
             f32x4 v[MMT_RIT], res[MMT_RIT];
             bf16x4 mk[MMT_RIT];
             float rs[MMT_RIT];
@@ -559,6 +570,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         if (TPR == 16) { s1 += __shfl_xor(s1, 8); s2 += __shfl_xor(s2, 8); }
         {
             const bool live = m < M;
+            const DropCfg& next_drop = sd.n;
             const float sigma = live ? 1.0f / rstd - p.eps : 1.f;
             const float k1 = s1 / (float)d, k2 = s2 / ((float)(d - 1) * sigma);
             for (int c = j * 4; c < ((KEEP & KEEP_AS) ? NP : d); c += 4 * TPR) {
@@ -650,7 +662,7 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
     sm.ldf = rowgemm_fw(EPI, LNPRO, p.KP, p.NP) + 4;
     sm.Gs = sm.Fs + (size_t)MMT_ROWS * sm.ldf;
     sm.Xs = nullptr; sm.A2 = nullptr; sm.ldx = 0; sm.lda2 = 0;
-    rowgemm_stage<EPI, LNPRO, ASRC_GLOBAL, 0, WIDE>(p, sm);
+    rowgemm_stage<EPI, LNPRO, ASRC_GLOBAL, 0, WIDE>(p, sm, stage_drops(p));
 }
 
 // ---- chained stages ------------------------------------------------------------------------------
@@ -715,10 +727,11 @@ __device__ __forceinline__ void ln_tile_out(const float* Xs, int ldx, const LnOu
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_post_attn_fwd_kernel(const RowChain3 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, false);
+    const StageDrops da = stage_drops(ch.a), db = stage_drops(ch.b), dc = stage_drops(ch.c);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X>(ch.a, sm);
-    rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2>(ch.b, sm);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X>(ch.c, sm);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X>(ch.a, sm, da);
+    rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2>(ch.b, sm, db);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X>(ch.c, sm, dc);
     if (ch.ln.y) ln_tile_out(sm.Xs, sm.ldx, ch.ln, ch.c.M);          // last layer: the stack's final LayerNorm, from the tile in LDS
 }
 
@@ -727,12 +740,13 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_post_attn_fwd4_kernel(const RowChain4 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, false);
+    const StageDrops da = stage_drops(ch.a), db = stage_drops(ch.b), dc = stage_drops(ch.c), dd = stage_drops(ch.d);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
     warm_weights(ch.d.W, ch.d.NP, ch.d.KP);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X>(ch.a, sm);
-    rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2>(ch.b, sm);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X>(ch.c, sm);
-    rowgemm_stage<EPI_FRAG, true, ASRC_X, 0>(ch.d, sm);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X>(ch.a, sm, da);
+    rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2>(ch.b, sm, db);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X>(ch.c, sm, dc);
+    rowgemm_stage<EPI_FRAG, true, ASRC_X, 0>(ch.d, sm, dd);
 }
 
 // Backward, from the layer-output gradient dx2 down to the attention core's operands:
@@ -743,10 +757,11 @@ template <bool WIDE>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_pre_attn_bwd_kernel(const RowChain3 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
+    const StageDrops da = stage_drops(ch.a), db = stage_drops(ch.b), dc = stage_drops(ch.c);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_A2>(ch.a, sm);
-    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, WIDE>(ch.b, sm);          // dx1 -> global (fp32) and, as the next A tile, LDS (bf16)
-    rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0>(ch.c, sm);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_A2>(ch.a, sm, da);
+    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, WIDE>(ch.b, sm, db);      // dx1 -> global (fp32) and, as the next A tile, LDS (bf16)
+    rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0>(ch.c, sm, dc);
 }
 
 
@@ -760,9 +775,10 @@ template <bool WIDE>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_bwd_boundary_kernel(const RowChain4 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
+    const StageDrops da = stage_drops(ch.a), db = stage_drops(ch.b), dc = stage_drops(ch.c), dd = stage_drops(ch.d);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP); warm_weights(ch.d.W, ch.d.NP, ch.d.KP);
-    rowgemm_stage<EPI_LNBWD, false, ASRC_GLOBAL, KEEP_AS, WIDE>(ch.a, sm); // layer l:   dx -> global (fp32) + next A tile (bf16, dropped)
-    rowgemm_stage<EPI_PLAIN, false, ASRC_AS, KEEP_A2>(ch.b, sm);           // layer l-1: dh
-    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, WIDE>(ch.c, sm);     //            dx1
-    rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0>(ch.d, sm);                  //            dO fragments + delta
+    rowgemm_stage<EPI_LNBWD, false, ASRC_GLOBAL, KEEP_AS, WIDE>(ch.a, sm, da); // layer l:   dx -> global (fp32) + next A tile (bf16, dropped)
+    rowgemm_stage<EPI_PLAIN, false, ASRC_AS, KEEP_A2>(ch.b, sm, db);           // layer l-1: dh
+    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, WIDE>(ch.c, sm, dc);     //            dx1
+    rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0>(ch.d, sm, dd);                  //            dO fragments + delta
 }
