@@ -231,9 +231,10 @@ static void carve_encoder(EncWs& W, const EncDims& D, void* base, bool train = t
 }
 
 // ------------------------------------------------------------------------------------ launch helpers
-template <int EPI, bool LN, bool WIDE = false>
+template <int EPI, bool LN, bool WIDE = false, bool DEVSEED = false>
 static int launch_rowgemm(const RowGemmParams& p, hipStream_t st, int site = S_OTHER) {
     if (EPI == EPI_LNBWD && !WIDE && p.no_gs) return launch_rowgemm<EPI_LNBWD, false, true>(p, st, site);      // d_model > 128: its own instance
+    if (EPI == EPI_PLAIN && !DEVSEED && p.seedword) return launch_rowgemm<EPI_PLAIN, LN, WIDE, true>(p, st, site);   // device-resident seed: its own instance
     if (!WIDE && (p.no_gs || p.kchunk)) return fail(MMT_EINVAL, "K-chunked staging / single-tile column sums exist for the LayerNorm-backward kernel only");
     const size_t lds = rowgemm_lds_bytes(EPI, LN, p.KP, p.NP, p.kchunk, p.no_gs != 0);
     if (lds > 160 * 1024) return fail(MMT_EUNSUPPORTED, "row GEMM tile needs %zu B of LDS (K=%d, N=%d)", lds, p.K, p.N);
@@ -241,13 +242,13 @@ static int launch_rowgemm(const RowGemmParams& p, hipStream_t st, int site = S_O
         return fail(MMT_EINVAL, "K-chunked staging needs a bf16 A matrix, a power-of-two chunk >= 64 and no A copy");
     static size_t configured = 0;           // per instantiation
     if (lds > configured) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<EPI, LN, WIDE>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&rowgemm_kernel<EPI, LN, WIDE, DEVSEED>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = 160 * 1024;
     }
     const int grid = (p.M + MMT_ROWS - 1) / MMT_ROWS;
     ProfScope prof(site, st);
-    hipLaunchKernelGGL((rowgemm_kernel<EPI, LN, WIDE>), dim3(grid), dim3(MMT_RTHREADS), lds, st, p);
+    hipLaunchKernelGGL((rowgemm_kernel<EPI, LN, WIDE, DEVSEED>), dim3(grid), dim3(MMT_RTHREADS), lds, st, p);
     LAUNCH_CHECK("rowgemm_kernel");
     return MMT_OK;
 }
@@ -271,13 +272,13 @@ static int launch_rowchain(K kernel, CH& ch, bool lnbwd, int site, const char* n
     const bool with_g = lnbwd && !(ch.a.no_gs || ch.b.no_gs || ch.c.no_gs);      // ... and a second fp32 tile unless the column sums recompute x-hat
     const size_t lds = rowchain_lds_bytes(ch, with_g);
     if (lds > 160 * 1024) return fail(MMT_EUNSUPPORTED, "fused row chain needs %zu B of LDS", lds);
-    static const void* configured[4] = {nullptr, nullptr, nullptr, nullptr};     // both chain kernels share this instantiation
+    static const void* configured[8] = {};       // every chain kernel of one argument type shares this instantiation
     const void* kp = reinterpret_cast<const void*>(kernel);
     bool seen = false;
-    for (int i = 0; i < 4; ++i) seen = seen || configured[i] == kp;
+    for (int i = 0; i < 8; ++i) seen = seen || configured[i] == kp;
     if (!seen) {
         HIP_TRY(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        for (int i = 0; i < 4; ++i) if (!configured[i]) { configured[i] = kp; break; }
+        for (int i = 0; i < 8; ++i) if (!configured[i]) { configured[i] = kp; break; }
     }
     ProfScope prof(site, st);
     hipLaunchKernelGGL(kernel, dim3((ch.a.M + MMT_ROWS - 1) / MMT_ROWS), dim3(MMT_RTHREADS), lds, st, ch);
@@ -531,13 +532,15 @@ static int encoder_forward_impl(const float* x, const float* mask, const float* 
                 RowChain4 c4; memset(&c4, 0, sizeof(c4));
                 c4.a = ch.a; c4.b = ch.b; c4.c = ch.c; c4.ldx = ch.ldx; c4.lda2 = ch.lda2;
                 c4.d = qkv_params(l + 1, nullptr);                 // A operand: the x2 tile in LDS
-                if ((rc = launch_rowchain(encoder_post_attn_fwd4_kernel, c4, false, S_CHAIN4_FWD, "encoder_post_attn_fwd4_kernel", st))) return rc;
+                if ((rc = launch_rowchain(devseed ? encoder_post_attn_fwd4_kernel<true> : encoder_post_attn_fwd4_kernel<false>, c4, false, S_CHAIN4_FWD,
+                                          "encoder_post_attn_fwd4_kernel", st))) return rc;
             } else {
                 if (l + 1 == D.N) {        // last layer: the stack's final LayerNorm runs on the output tile while it is in LDS
                     const float* Pf = params + (size_t)D.N * L.stride();
                     ch.ln.a = Pf; ch.ln.b = Pf + d; ch.ln.eps = eps; ch.ln.y = y; ch.ln.stats = W.statsf; ch.ln.d = d;
                 }
-                if ((rc = launch_rowchain(encoder_post_attn_fwd_kernel, ch, false, S_OUTPROJ, "encoder_post_attn_fwd_kernel", st))) return rc;
+                if ((rc = launch_rowchain(devseed ? encoder_post_attn_fwd_kernel<true> : encoder_post_attn_fwd_kernel<false>, ch, false, S_OUTPROJ,
+                                          "encoder_post_attn_fwd_kernel", st))) return rc;
                 if (l + 1 < D.N) {
                     RowGemmParams p = qkv_params(l + 1, w.xout);
                     if ((rc = launch_rowgemm<EPI_FRAG, true>(p, st, S_LN1_QKV))) return rc;
@@ -677,8 +680,9 @@ static int encoder_backward_impl(const float* dy, const float* x, const float* m
         const LayerWs& w = W.lw[l];
         if (l == D.N - 1 || !boundary) {
             RowChain3 ch; build_chain(l, ch);
-            if (ch.b.no_gs) rc = launch_rowchain(encoder_pre_attn_bwd_kernel<true>, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st);
-            else rc = launch_rowchain(encoder_pre_attn_bwd_kernel<false>, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st);
+            auto k3 = ch.b.no_gs ? (devseed ? encoder_pre_attn_bwd_kernel<true, true> : encoder_pre_attn_bwd_kernel<true, false>)
+                                 : (devseed ? encoder_pre_attn_bwd_kernel<false, true> : encoder_pre_attn_bwd_kernel<false, false>);
+            rc = launch_rowchain(k3, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st);
             if (rc) return rc;
         }
         if ((rc = launch_attn_bwd(L.DKP, w.QR, w.KR, w.VR, W.dOR, w.lse, W.delta, mask,
@@ -692,8 +696,9 @@ static int encoder_backward_impl(const float* dy, const float* x, const float* m
             c4.a.seedword = seedword;
             c4.b = below.a; c4.c = below.b; c4.d = below.c; c4.ldx = 0; c4.lda2 = below.lda2;
             if (c4.a.no_gs != c4.c.no_gs) { c4.a.no_gs = c4.c.no_gs = 1; }        // (one WIDE flag per kernel: K-chunking alone implies it)
-            if (c4.a.no_gs) rc = launch_rowchain(encoder_bwd_boundary_kernel<true>, c4, true, S_BWD_BOUNDARY, "encoder_bwd_boundary_kernel", st, L.DP);
-            else rc = launch_rowchain(encoder_bwd_boundary_kernel<false>, c4, true, S_BWD_BOUNDARY, "encoder_bwd_boundary_kernel", st, L.DP);
+            auto k4 = c4.a.no_gs ? (devseed ? encoder_bwd_boundary_kernel<true, true> : encoder_bwd_boundary_kernel<true, false>)
+                                 : (devseed ? encoder_bwd_boundary_kernel<false, true> : encoder_bwd_boundary_kernel<false, false>);
+            rc = launch_rowchain(k4, c4, true, S_BWD_BOUNDARY, "encoder_bwd_boundary_kernel", st, L.DP);
             if (rc) return rc;
         } else {
             RowGemmParams p = build_qkv(l, dxin);

@@ -142,18 +142,17 @@ __device__ __forceinline__ ColPos col_pos(int n, int HD, int DKP) {
 // WIDE: the d_model > 128 variant of a LayerNorm-backward stage — K-chunked A staging (RowGemmParams::kchunk) and column sums without the
 // second fp32 tile (RowGemmParams::no_gs, which the host sets to match).  Its own instantiation, so that the d_model <= 128 kernels
 // carry neither the extra barriers nor the registers of the batched re-reads.
-// The stage's dropout streams with their keys resolved (device-resident seed: fetched from the workspace's seed block, common.h).  The
-// kernels resolve the keys of ALL their stages at entry, so the scalar loads run behind the first stage's staging instead of in front
-// of each stage's first masked element.
-struct StageDrops { DropCfg a, e, n; };
-__device__ __forceinline__ StageDrops stage_drops(const RowGemmParams& p) {
-    StageDrops d;
-    d.a = drop_resolve(p.a_drop, p.seedword); d.e = drop_resolve(p.drop, p.seedword); d.n = drop_resolve(p.next_drop, p.seedword);
-    return d;
+// W-fragment ring depth of a stage: PFD k-blocks of 64 per wave.  The stand-alone LayerNorm-backward instance (bwd_qkv: K = 3 h d_k, six
+// k-blocks at d_model = 128, 58 VGPRs) keeps six blocks in flight — with two, four L2 round trips per tile were exposed; the chained
+// kernels sit at the 128-VGPR cap and keep two.
+template <int EPI, int ASRC, int KEEP, bool WIDE> __host__ __device__ constexpr int rowgemm_pfd() {
+    return (EPI == EPI_LNBWD && ASRC == ASRC_GLOBAL && KEEP == 0) ? (WIDE ? 4 : 6) : 2;
 }
-
-template <int EPI, bool LNPRO, int ASRC, int KEEP, bool WIDE = false>
-__device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowSmem& sm, const StageDrops& sd) {
+// DEVSEED: the stage's DropCfgs carry stream slots and the keys come from the workspace's seed block (common.h drop_resolve: one scalar
+// load where a mask is first needed).  Its own instantiation: the by-value kernels read the keys straight from their arguments and carry
+// none of it (these kernels run out of scalar registers as it is).
+template <int EPI, bool LNPRO, int ASRC, int KEEP, bool DEVSEED, bool WIDE = false>
+__device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowSmem& sm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int KP = p.KP, NP = p.NP, K = p.K, M = p.M;
     // K-chunked staging: kc columns of the A tile in LDS at a time (kc == KP: all of it, the usual case)
@@ -170,10 +169,10 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     PHASE_DECL
 
     // W fragments (straight from L2, ~1k cycles away) travel through a ring of PFD k-blocks per wave.  The first PFD blocks of the
-    // first chunk go in flight NOW: their latency overlaps the A-tile staging.  The stand-alone LayerNorm-backward instance
-    // (bwd_qkv: K = 3 h d_k, six k-blocks at d_model = 128, 58 VGPRs) keeps six blocks in flight — with two, four L2 round trips
-    // per tile were exposed; the chained kernels sit at the 128-VGPR cap and keep two.
-    constexpr int PFD = (EPI == EPI_LNBWD && ASRC == ASRC_GLOBAL && KEEP == 0) ? (WIDE ? 4 : 6) : 2;
+    // first chunk go in flight NOW: their latency overlaps the A-tile staging.  (Requesting the NEXT stage's first blocks behind a stage's
+    // last k-loop, so that they travel during its epilogue, was measured: the forward chain got 5 us per step slower — the ring's 16
+    // registers stay live across the epilogue of kernels that sit at the 128-VGPR cap.)
+    constexpr int PFD = rowgemm_pfd<EPI, ASRC, KEEP, WIDE>();
     bf16x8 wf[PFD][2][MMT_WNT];                                   // [slot][k half: +0 / +32][16-column tile of the wave]
     auto w_load = [&](int slot, int nb, int kb) {                 // slot and the guard are compile-time / wave-uniform
         const bf16* wr = p.W + (size_t)(nb + l15) * KP + 8 * lq + kb;
@@ -249,7 +248,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         }
     } else if (ASRC == ASRC_X) {
         // fp32 tile kept by the previous stage -> bf16 (optionally through the dropout mask of index m*KP + k)
-        const DropCfg& a_drop = sd.a;
+        const DropCfg a_drop = DEVSEED ? drop_resolve(p.a_drop, p.seedword) : p.a_drop;
         for (int row = tid >> 4; row < ROWS; row += MMT_RTHREADS / 16)
         for (int c = (tid & 15) * 4; c < KP; c += 64) {
             const int m = m0 + row;
@@ -272,7 +271,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         stage_a16(0);
     } else {
         const float* A = static_cast<const float*>(p.A);
-        const DropCfg& a_drop = sd.a;
+        const DropCfg a_drop = DEVSEED ? drop_resolve(p.a_drop, p.seedword) : p.a_drop;
         for (int row = tid >> 4; row < ROWS; row += MMT_RTHREADS / 16)
         for (int c = (tid & 15) * 4; c < KP; c += 64) {
             const int m = m0 + row;
@@ -367,7 +366,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             // (non-restrict) output pointers would otherwise fence the later tasks' loads and serialise 4 L2 round trips.
             const int cg = tid & 31, n = n0 + cg * 4, rbase = tid >> 5;
             const bool col_ok = n < NP;
-            const DropCfg& e_drop = sd.e;
+            const DropCfg e_drop = DEVSEED ? drop_resolve(p.drop, p.seedword) : p.drop;
             f32x4 v[MMT_RIT], res[MMT_RIT];
             bf16x4 mk[MMT_RIT];
             float rs[MMT_RIT];
@@ -570,7 +569,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         if (TPR == 16) { s1 += __shfl_xor(s1, 8); s2 += __shfl_xor(s2, 8); }
         {
             const bool live = m < M;
-            const DropCfg& next_drop = sd.n;
+            const DropCfg next_drop = DEVSEED ? drop_resolve(p.next_drop, p.seedword) : p.next_drop;
             const float sigma = live ? 1.0f / rstd - p.eps : 1.f;
             const float k1 = s1 / (float)d, k2 = s2 / ((float)(d - 1) * sigma);
             for (int c = j * 4; c < ((KEEP & KEEP_AS) ? NP : d); c += 4 * TPR) {
@@ -653,7 +652,7 @@ __device__ __forceinline__ void warm_weights(const bf16* W, int NP, int KP) {
 }
 
 // ---- single stage ------------------------------------------------------------------------------
-template <int EPI, bool LNPRO, bool WIDE = false>
+template <int EPI, bool LNPRO, bool WIDE = false, bool DEVSEED = false>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void rowgemm_kernel(const RowGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     RowSmem sm;
@@ -662,7 +661,7 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
     sm.ldf = rowgemm_fw(EPI, LNPRO, p.KP, p.NP) + 4;
     sm.Gs = sm.Fs + (size_t)MMT_ROWS * sm.ldf;
     sm.Xs = nullptr; sm.A2 = nullptr; sm.ldx = 0; sm.lda2 = 0;
-    rowgemm_stage<EPI, LNPRO, ASRC_GLOBAL, 0, WIDE>(p, sm, stage_drops(p));
+    rowgemm_stage<EPI, LNPRO, ASRC_GLOBAL, 0, DEVSEED, WIDE>(p, sm);
 }
 
 // ---- chained stages ------------------------------------------------------------------------------
@@ -724,44 +723,43 @@ __device__ __forceinline__ void ln_tile_out(const float* Xs, int ldx, const LnOu
 // Forward, after the attention core of a layer:   x1 = x + drop(ctx Wo^T + bo)        (out-proj + residual; x1 kept in LDS)
 //                                                 hid = drop(relu(LN2(x1) W1^T + b1))  (hid kept in LDS as the next A tile)
 //                                                 x2 = x1 + drop(hid W2^T + b2)        (residual read from LDS)
+template <bool DEVSEED>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_post_attn_fwd_kernel(const RowChain3 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, false);
-    const StageDrops da = stage_drops(ch.a), db = stage_drops(ch.b), dc = stage_drops(ch.c);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X>(ch.a, sm, da);
-    rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2>(ch.b, sm, db);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X>(ch.c, sm, dc);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X, DEVSEED>(ch.a, sm);
+    rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2, DEVSEED>(ch.b, sm);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X, DEVSEED>(ch.c, sm);
     if (ch.ln.y) ln_tile_out(sm.Xs, sm.ldx, ch.ln, ch.c.M);          // last layer: the stack's final LayerNorm, from the tile in LDS
 }
 
 // The same chain followed by the NEXT layer's LayerNorm-1 + Q/K/V projection (its input x2 is already in LDS): every
 // layer but the last.  One launch and one round trip of the residual stream less per layer.
+template <bool DEVSEED>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_post_attn_fwd4_kernel(const RowChain4 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, false);
-    const StageDrops da = stage_drops(ch.a), db = stage_drops(ch.b), dc = stage_drops(ch.c), dd = stage_drops(ch.d);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
     warm_weights(ch.d.W, ch.d.NP, ch.d.KP);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X>(ch.a, sm, da);
-    rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2>(ch.b, sm, db);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X>(ch.c, sm, dc);
-    rowgemm_stage<EPI_FRAG, true, ASRC_X, 0>(ch.d, sm, dd);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X, DEVSEED>(ch.a, sm);
+    rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2, DEVSEED>(ch.b, sm);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X, DEVSEED>(ch.c, sm);
+    rowgemm_stage<EPI_FRAG, true, ASRC_X, 0, false>(ch.d, sm);
 }
 
 // Backward, from the layer-output gradient dx2 down to the attention core's operands:
 //     dh  = (drop'(dx2) W2) * relu'(hid) * drop'          (dh kept in LDS as the next A tile; dx2^T, dh^T emitted for dW)
 //     dx1 = dx2 + LN2bwd(dh W1)                            (drop'(dx1) kept in LDS as the next A tile)
 //     dO  = drop'(dx1) Wo  -> fragment layouts + delta     (dx1^T emitted for dW)
-template <bool WIDE>
+template <bool WIDE, bool DEVSEED>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_pre_attn_bwd_kernel(const RowChain3 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
-    const StageDrops da = stage_drops(ch.a), db = stage_drops(ch.b), dc = stage_drops(ch.c);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_A2>(ch.a, sm, da);
-    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, WIDE>(ch.b, sm, db);      // dx1 -> global (fp32) and, as the next A tile, LDS (bf16)
-    rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0>(ch.c, sm, dc);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_A2, DEVSEED>(ch.a, sm);
+    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(ch.b, sm);      // dx1 -> global (fp32) and, as the next A tile, LDS (bf16)
+    rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(ch.c, sm);
 }
 
 
@@ -771,14 +769,13 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
 // workgroup barriers, each draining the stores, in between) and, dropped and rounded to bf16, straight into the next A tile.  One
 // launch and one staging pass less per layer than `bwd_qkv+ln1` followed by the chain.  (WIDE: 83 KB of LDS at d_model = 256, one
 // workgroup per CU — at that width two workgroups sharing a CU take twice as long each anyway)
-template <bool WIDE>
+template <bool WIDE, bool DEVSEED>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_bwd_boundary_kernel(const RowChain4 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
-    const StageDrops da = stage_drops(ch.a), db = stage_drops(ch.b), dc = stage_drops(ch.c), dd = stage_drops(ch.d);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP); warm_weights(ch.d.W, ch.d.NP, ch.d.KP);
-    rowgemm_stage<EPI_LNBWD, false, ASRC_GLOBAL, KEEP_AS, WIDE>(ch.a, sm, da); // layer l:   dx -> global (fp32) + next A tile (bf16, dropped)
-    rowgemm_stage<EPI_PLAIN, false, ASRC_AS, KEEP_A2>(ch.b, sm, db);           // layer l-1: dh
-    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, WIDE>(ch.c, sm, dc);     //            dx1
-    rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0>(ch.d, sm, dd);                  //            dO fragments + delta
+    rowgemm_stage<EPI_LNBWD, false, ASRC_GLOBAL, KEEP_AS, DEVSEED, WIDE>(ch.a, sm);        // layer l:   dx -> global (fp32) + next A tile (bf16, dropped)
+    rowgemm_stage<EPI_PLAIN, false, ASRC_AS, KEEP_A2, DEVSEED>(ch.b, sm);     // layer l-1: dh
+    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(ch.c, sm);      //            dx1
+    rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(ch.d, sm);                                               //            dO fragments + delta
 }
