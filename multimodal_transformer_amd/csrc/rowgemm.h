@@ -720,6 +720,28 @@ __device__ __forceinline__ void ln_tile_out(const float* Xs, int ldx, const LnOu
     }
 }
 
+// Stage roles of the chained kernels.  rowgemm_stage() serves every affine map of the library and decides most of its options at run
+// time; in a chain each stage's role is fixed, and what mmt_encoder_forward / _backward (api.hip) leave unset for that role is pinned
+// here in a local copy of the stage's parameters: the copies are constants to the compiler, so the options' code — the tanh / sigmoid
+// epilogues, the ReLU-mask, row-scale and second-output paths, K-chunked staging — and their scalar branch / exec-mask bookkeeping
+// (40 % of the static instruction stream of these kernels was scalar) drop out of the kernel.  (The fragment-epilogue stages keep
+// their parameters where they are: they index fragR[] dynamically, which would put a local copy into scratch memory.)
+__device__ __forceinline__ RowGemmParams role_plain(RowGemmParams p) {          // bias + dropout (+ residual), fp32 out: out-proj, FFN2
+    p.act = 0; p.relu_mask = nullptr; p.rowscale = nullptr; p.out_bf16 = nullptr; p.A_out = nullptr; p.a_drop.thr16 = 0;
+    p.next_drop.thr16 = 0; p.kchunk = 0; p.ln_a = nullptr; p.stats = nullptr;
+    return p;
+}
+__device__ __forceinline__ RowGemmParams role_ffn1(RowGemmParams p) {           // LayerNorm + bias + ReLU + dropout, bf16 out and copy of the A tile
+    p.act = 1; p.relu_mask = nullptr; p.rowscale = nullptr; p.out_f32 = nullptr; p.residual = nullptr; p.a_drop.thr16 = 0;
+    p.next_drop.thr16 = 0; p.kchunk = 0;
+    return p;
+}
+__device__ __forceinline__ RowGemmParams role_bwd_relu(RowGemmParams p) {       // dh = (drop'(g) W) * relu'(hid): bf16 out, copy of the A tile
+    p.act = 0; p.bias = nullptr; p.rowscale = nullptr; p.out_f32 = nullptr; p.residual = nullptr; p.drop.thr16 = 0;
+    p.next_drop.thr16 = 0; p.kchunk = 0; p.ln_a = nullptr; p.stats = nullptr;
+    return p;
+}
+
 // Forward, after the attention core of a layer:   x1 = x + drop(ctx Wo^T + bo)        (out-proj + residual; x1 kept in LDS)
 //                                                 hid = drop(relu(LN2(x1) W1^T + b1))  (hid kept in LDS as the next A tile)
 //                                                 x2 = x1 + drop(hid W2^T + b2)        (residual read from LDS)
@@ -728,9 +750,9 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, false);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X, DEVSEED>(ch.a, sm);
-    rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2, DEVSEED>(ch.b, sm);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X, DEVSEED>(ch.c, sm);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X, DEVSEED>(role_plain(ch.a), sm);
+    rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2, DEVSEED>(role_ffn1(ch.b), sm);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X, DEVSEED>(role_plain(ch.c), sm);
     if (ch.ln.y) ln_tile_out(sm.Xs, sm.ldx, ch.ln, ch.c.M);          // last layer: the stack's final LayerNorm, from the tile in LDS
 }
 
@@ -742,9 +764,9 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
     const RowSmem sm = rowchain_carve(smem, ch, false);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
     warm_weights(ch.d.W, ch.d.NP, ch.d.KP);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X, DEVSEED>(ch.a, sm);
-    rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2, DEVSEED>(ch.b, sm);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X, DEVSEED>(ch.c, sm);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X, DEVSEED>(role_plain(ch.a), sm);
+    rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2, DEVSEED>(role_ffn1(ch.b), sm);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X, DEVSEED>(role_plain(ch.c), sm);
     rowgemm_stage<EPI_FRAG, true, ASRC_X, 0, false>(ch.d, sm);
 }
 
@@ -757,7 +779,7 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
-    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_A2, DEVSEED>(ch.a, sm);
+    rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_A2, DEVSEED>(role_bwd_relu(ch.a), sm);
     rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(ch.b, sm);      // dx1 -> global (fp32) and, as the next A tile, LDS (bf16)
     rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(ch.c, sm);
 }
@@ -775,7 +797,7 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
     const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP); warm_weights(ch.d.W, ch.d.NP, ch.d.KP);
     rowgemm_stage<EPI_LNBWD, false, ASRC_GLOBAL, KEEP_AS, DEVSEED, WIDE>(ch.a, sm);        // layer l:   dx -> global (fp32) + next A tile (bf16, dropped)
-    rowgemm_stage<EPI_PLAIN, false, ASRC_AS, KEEP_A2, DEVSEED>(ch.b, sm);     // layer l-1: dh
-    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(ch.c, sm);      //            dx1
-    rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(ch.d, sm);                                               //            dO fragments + delta
+    rowgemm_stage<EPI_PLAIN, false, ASRC_AS, KEEP_A2, DEVSEED>(role_bwd_relu(ch.b), sm);                     // layer l-1: dh
+    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(ch.c, sm);                              //            dx1
+    rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(ch.d, sm);                                  //            dO fragments + delta
 }
