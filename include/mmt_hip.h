@@ -163,6 +163,10 @@ int mmt_softmax_mul_backward(const float* dout, const float* att, const float* v
 /* out[c] = sum over `rows` rows of x (row stride ld): gradient of a row that the forward broadcast over the batch. */
 int mmt_colsum(const float* x, float* out, int rows, int cols, int ld, mmt_stream_t stream);
 
+/* accum[0] |= word[0] on the device, in stream order: keeps a kernel's device error word (mmt_lstm_scan_*: first word of the workspace)
+ * beyond the life of its workspace, also inside a captured hipGraph.  Both pointers are device memory. */
+int mmt_error_accumulate(const uint32_t* word, uint32_t* accum, mmt_stream_t stream);
+
 /* ---- LSTM recurrence over T steps with the input projection already applied.
  * Replaces the per-step nn.LSTMCell loop of MFN.forward       transformer/MFT/multiTransformer.py:200-208
  * and the per-step nn.LSTM call of the SFT decoder            transformer/SFT/multiTransformer.py:471-476.

@@ -47,6 +47,7 @@ SIGNATURES = {
     "mmt_softmax_mul_forward": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "mmt_softmax_mul_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "mmt_colsum": (_I, [_P, _P, _I, _I, _I, _P]),
+    "mmt_error_accumulate": (_I, [_P, _P, _P]),
     "mmt_lstm_scan_workspace_bytes": (_SZ, [_I]),
     "mmt_lstm_scan_forward": (_I, [_P] * 8 + [_SZ] + [_I] * 3 + [_P]),
     "mmt_lstm_scan_backward": (_I, [_P] * 10 + [_SZ] + [_I] * 3 + [_P]),
@@ -175,37 +176,41 @@ POOL = WorkspacePool()
 
 class DeviceErrorWatch:
     """Device error words of asynchronous kernels (today: the exchange time-out of the four-CU LSTM scans,
-    include/mmt_hip.h mmt_lstm_scan_*).  ``watch`` copies the word to a pinned host slot behind the launch; ``poll`` (called at
-    every later eager launch, never blocking) and ``check`` (blocking) raise if a drained launch left a non-zero word.
-    Inside a hipGraph capture the copy becomes a node of the graph with a FIXED slot: every replay refreshes it, and ``check``
-    reads those slots too (``poll`` cannot: no event marks the end of a replay).  The pinned ring must exist before a capture
-    starts (pinned allocations are illegal inside one): ``prepare`` makes it, and so does any eager ``watch`` — a warm-up step."""
+    include/mmt_hip.h mmt_lstm_scan_*).  Eager launches: ``watch`` copies the word to a pinned host slot behind the launch; ``poll``
+    (called at every later eager launch, never blocking) and ``check`` (blocking) raise if a drained launch left a non-zero word.
+    Inside a hipGraph capture the word is OR-ed into a persistent device word by a kernel of the captured sequence
+    (``mmt_error_accumulate``; a device-to-host copy node was seen to run out of order in the replayed graph), and ``check`` reads
+    that word after synchronising.  The persistent word must exist before a capture starts: ``prepare`` makes it, and so does any eager
+    ``watch`` — a warm-up step."""
 
     SLOTS = 2048                    # ring of pinned host words for eager launches
-    GRAPH_SLOTS = 256               # fixed slots of captured launches (never recycled)
 
     def __init__(self):
         self._pending = []          # (slot, event, description)
-        self._graph = []            # (slot, description) of captured launches
         self._mutex = threading.Lock()
         self._host = None
+        self._accum = {}            # device -> persistent int32 word for captured launches
+        self._captured = []         # descriptions of the captured launches
         self._next = 0
 
-    def prepare(self):
+    def prepare(self, device=None):
         with self._mutex:
             if self._host is None:
-                self._host = torch.zeros(self.SLOTS + self.GRAPH_SLOTS, dtype=torch.int32).pin_memory()
+                self._host = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
+            if device is not None and str(device) not in self._accum:
+                self._accum[str(device)] = torch.zeros(1, dtype=torch.int32, device=device)
 
     def watch(self, dev_word, what):
         if torch.cuda.is_current_stream_capturing():
+            acc = self._accum.get(str(dev_word.device))
+            if acc is None:
+                return              # nothing ran eagerly before the capture: this launch stays unwatched
+            check(load().mmt_error_accumulate(ptr(dev_word), ptr(acc), stream_ptr()))
             with self._mutex:
-                if self._host is None or len(self._graph) >= self.GRAPH_SLOTS:
-                    return          # no pinned ring yet (nothing ran eagerly before the capture) / table full: this launch stays unwatched
-                slot = self.SLOTS + len(self._graph)
-                self._graph.append((slot, what + " [hipGraph replay]"))
-            self._host[slot:slot + 1].copy_(dev_word, non_blocking=True)         # a memcpy node: refreshed by every replay
+                if what not in self._captured:
+                    self._captured.append(what)
             return
-        self.prepare()
+        self.prepare(dev_word.device)
         with self._mutex:
             slot, self._next = self._next, (self._next + 1) % self.SLOTS
             lapped = any(e[0] == slot for e in self._pending)                    # the slot's previous launch has not been looked at yet
@@ -238,14 +243,14 @@ class DeviceErrorWatch:
         torch.cuda.synchronize()
         with self._mutex:
             entries, self._pending = self._pending, []
-            graph = list(self._graph)
+            accs = list(self._accum.values())
         for slot, _, what in entries:
             if int(self._host[slot]) != 0:
                 self._raise(what)
-        for slot, what in graph:
-            if int(self._host[slot]) != 0:
-                self._host[slot] = 0
-                self._raise(what)
+        for acc in accs:
+            if int(acc.item()) != 0:
+                acc.zero_()
+                self._raise("a launch replayed from a hipGraph (%s)" % "; ".join(self._captured[-4:]))
 
 
 ERRORS = DeviceErrorWatch()

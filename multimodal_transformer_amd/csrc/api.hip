@@ -1136,6 +1136,12 @@ extern "C" int mmt_softmax_mul_backward(const float* dout, const float* att, con
     LAUNCH_CHECK("softmax_mul_bwd_kernel");
     return MMT_OK;
 }
+extern "C" int mmt_error_accumulate(const uint32_t* word, uint32_t* accum, mmt_stream_t stream) {
+    if (!word || !accum) return fail(MMT_EINVAL, "null pointer argument");
+    hipLaunchKernelGGL(error_accumulate_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), word, accum);
+    LAUNCH_CHECK("error_accumulate_kernel");
+    return MMT_OK;
+}
 extern "C" int mmt_colsum(const float* x, float* out, int rows, int cols, int ld, mmt_stream_t stream) {
     if (!x || !out) return fail(MMT_EINVAL, "null pointer argument");
     if (rows <= 0 || cols <= 0 || ld < cols) return fail(MMT_EINVAL, "bad shape rows=%d cols=%d ld=%d", rows, cols, ld);
@@ -1210,7 +1216,11 @@ extern "C" int mmt_lstm_scan_forward(const float* gx, const float* W_rec, const 
     const int cl_grid = 32 * ((B + 7) / 8);
     const int cl_fit = cl4_fits(&lstm_scan_fwd_cl4_kernel<3>, 0);
     const bool cluster = W.HPAD == 256 && B <= 32 && !no_cluster && cl_fit;
-    HIP_TRY(hipMemsetAsync(W.err, 0, MMT_SCAN_ERR_BYTES + (cluster ? W.xb_bytes : 0), st));    // error word (+ exchange granules)
+    {   // error word (+ exchange granules) cleared by a kernel of the launch sequence (not hipMemsetAsync: see zero_fill_kernel)
+        const size_t nw = (MMT_SCAN_ERR_BYTES + (cluster ? W.xb_bytes : 0)) / sizeof(unsigned);
+        hipLaunchKernelGGL(zero_fill_kernel, dim3(grid_for(nw)), dim3(256), 0, st, W.err, nw);
+        LAUNCH_CHECK("zero_fill_kernel");
+    }
     if (cluster) {       // four CUs per sequence, weights fully register-resident (scan_cluster.h)
         hipLaunchKernelGGL((lstm_scan_fwd_cl4_kernel<3>), dim3(cl_grid), dim3(256), 0, st,
                            gx, W.Wf, h0, c0, h_all, c_all, acts, W.xb, W.err, T, B, H, W.HP16);
@@ -1258,7 +1268,11 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
     static const bool no_cluster = getenv("MMT_NO_CLUSTER_SCAN") != nullptr;
     const int cl_fit = cl4_fits(&lstm_scan_bwd_cl4_kernel<2>, 1);
     const bool cluster = W.HPAD == 256 && B <= 32 && !no_cluster && cl_fit;
-    HIP_TRY(hipMemsetAsync(W.err, 0, MMT_SCAN_ERR_BYTES + (cluster ? W.xb_bytes : 0), st));
+    {   // error word (+ exchange granules) cleared by a kernel of the launch sequence (not hipMemsetAsync: see zero_fill_kernel)
+        const size_t nw = (MMT_SCAN_ERR_BYTES + (cluster ? W.xb_bytes : 0)) / sizeof(unsigned);
+        hipLaunchKernelGGL(zero_fill_kernel, dim3(grid_for(nw)), dim3(256), 0, st, W.err, nw);
+        LAUNCH_CHECK("zero_fill_kernel");
+    }
     if (cluster) {
         hipLaunchKernelGGL((lstm_scan_bwd_cl4_kernel<2>), dim3(32 * ((B + 7) / 8)), dim3(256), 0, st,
                            dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, W.xb, W.err, T, B, H, W.HP16);

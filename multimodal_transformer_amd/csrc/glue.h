@@ -96,3 +96,17 @@ __global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ o
     for (int r = 0; r < rows; ++r) s += x[(size_t)r * ld + c];
     out[c] = s;
 }
+
+// accum[0] |= word[0]: a device error word (e.g. the four-CU LSTM scans' time-out flag, first word of their workspace) folded into a word
+// that outlives the workspace, as a kernel of the launch sequence — so it is ordered like the kernels around it in a captured hipGraph
+// too (a device-to-host copy node recorded behind the scan was seen to run as a root node of the replayed graph).
+__global__ void error_accumulate_kernel(const unsigned* __restrict__ word, unsigned* __restrict__ accum) {
+    if (word[0]) atomicOr(accum, word[0]);
+}
+
+// p[0 .. n) = 0 (dwords).  Used instead of hipMemsetAsync: under hipGraph replay on ROCm 7.2 a captured memset node was seen to leave
+// other bytes than the ones asked for from the second replay on (tools note in DESIGN.md), and the four-CU scans rely on their exchange
+// granules and error word being cleared before every launch.
+__global__ void zero_fill_kernel(unsigned* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}

@@ -141,13 +141,15 @@ def test_encoder_gradients_share_one_flat_buffer(dev):
 
 
 def test_default_model_under_hipgraph_replay(dev):
-    """the reference-default SFT model (embed_dim 256: four-CU LSTM scans with per-launch zeroed exchange granules) captured in
-    a hipGraph and replayed: every replay must reproduce the eager result bit for bit (eval mode)"""
-    from multimodal_transformer_amd import multiTransformer as MT
+    """the reference-default SFT model (embed_dim 256: four-CU LSTM scans whose exchange granules and error word are cleared at every
+    launch) captured in a hipGraph and replayed on a DIFFERENT input at every replay: each replay must reproduce the eager result of
+    its own input bit for bit (eval mode) — stale exchange state of the previous replay would show — and leave the device error word clear"""
+    from multimodal_transformer_amd import multiTransformer as MT, functional as F
     torch.manual_seed(3)
     B, T = 4, 40
     model = MT.NLPTransformer(512, device=dev).eval()
-    x = torch.tanh(torch.randn(B, T, 512, device=dev))
+    xs = [torch.tanh(torch.randn(B, T, 512, device=dev)) for _ in range(3)]
+    x = xs[0].clone()
     mask = torch.ones(B, T, 1, device=dev)
     params = list(model.parameters())
 
@@ -158,23 +160,28 @@ def test_default_model_under_hipgraph_replay(dev):
         y.sum().backward()
         return y
 
-    y_ref = step().detach().clone()
-    g_ref = params[0].grad.detach().clone()
+    refs = []
+    for xi in xs:                                      # eager references (also the warm-up a capture needs)
+        x.copy_(xi)
+        y_ref = step().detach().clone()                # (no reference to the autograd graph may survive: its AccumulateGrad nodes
+        refs.append((y_ref, params[0].grad.detach().clone()))      #  would stay bound to this stream and break the capture below)
+    F.check_device_errors()
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-        for _ in range(2):
-            step()
+        step()
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         y_static = step()
-    for _ in range(3):
+    for i in (1, 2, 0, 1):
+        x.copy_(xs[i])
         g.replay()
         torch.cuda.synchronize()
-        assert torch.equal(y_static, y_ref)
-        assert torch.equal(params[0].grad, g_ref)
+        assert torch.equal(y_static, refs[i][0]), "replay on input %d" % i
+        assert torch.equal(params[0].grad, refs[i][1]), "replay on input %d" % i
+    F.check_device_errors()                            # the captured scans fold their error words into a device word that this reads
 
 
 @pytest.mark.parametrize("d,h,B,T,p", [(128, 8, 3, 300, 0.1), (256, 8, 2, 70, 0.1), (40, 4, 2, 33, 0.0)])
