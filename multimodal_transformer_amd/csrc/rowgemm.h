@@ -516,7 +516,8 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                     bf16x8 o;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { o[i] = (bf16)lo[i]; o[4 + i] = (bf16)hi[i]; }
-                    *reinterpret_cast<bf16x8*>(p.fragR[cj.wi] + (size_t)(sp.b * p.h + cj.head) * szR + fragR_index(sp.t, cj.e, p.DKP)) = o;
+                    bf16* const fr = cj.wi == 0 ? p.fragR[0] : (cj.wi == 1 ? p.fragR[1] : p.fragR[2]);      // (selects, not a dynamic index: a local copy of the parameters stays in registers)
+                    *reinterpret_cast<bf16x8*>(fr + (size_t)(sp.b * p.h + cj.head) * szR + fragR_index(sp.t, cj.e, p.DKP)) = o;
                 }
             }
         }
@@ -724,8 +725,7 @@ __device__ __forceinline__ void ln_tile_out(const float* Xs, int ldx, const LnOu
 // time; in a chain each stage's role is fixed, and what mmt_encoder_forward / _backward (api.hip) leave unset for that role is pinned
 // here in a local copy of the stage's parameters: the copies are constants to the compiler, so the options' code — the tanh / sigmoid
 // epilogues, the ReLU-mask, row-scale and second-output paths, K-chunked staging — and their scalar branch / exec-mask bookkeeping
-// (40 % of the static instruction stream of these kernels was scalar) drop out of the kernel.  (The fragment-epilogue stages keep
-// their parameters where they are: they index fragR[] dynamically, which would put a local copy into scratch memory.)
+// (40 % of the static instruction stream of these kernels was scalar) drop out of the kernel.
 __device__ __forceinline__ RowGemmParams role_plain(RowGemmParams p) {          // bias + dropout (+ residual), fp32 out: out-proj, FFN2
     p.act = 0; p.relu_mask = nullptr; p.rowscale = nullptr; p.out_bf16 = nullptr; p.A_out = nullptr; p.a_drop.thr16 = 0;
     p.next_drop.thr16 = 0; p.kchunk = 0; p.ln_a = nullptr; p.stats = nullptr;
@@ -734,6 +734,19 @@ __device__ __forceinline__ RowGemmParams role_plain(RowGemmParams p) {          
 __device__ __forceinline__ RowGemmParams role_ffn1(RowGemmParams p) {           // LayerNorm + bias + ReLU + dropout, bf16 out and copy of the A tile
     p.act = 1; p.relu_mask = nullptr; p.rowscale = nullptr; p.out_f32 = nullptr; p.residual = nullptr; p.a_drop.thr16 = 0;
     p.next_drop.thr16 = 0; p.kchunk = 0;
+    return p;
+}
+__device__ __forceinline__ RowGemmParams role_qkv(RowGemmParams p) {            // LayerNorm + Q/K/V projection -> attention operand fragments
+    p.delta = nullptr; p.ctx = nullptr; p.scale_first = 1; p.nwhich = 3; p.a_drop.thr16 = 0; p.drop.thr16 = 0; p.next_drop.thr16 = 0; p.kchunk = 0;
+    return p;
+}
+__device__ __forceinline__ RowGemmParams role_dO(RowGemmParams p) {             // dO = drop'(dx1) Wo -> fragments + delta, A tile already in LDS
+    p.bias = nullptr; p.scale_first = 0; p.rowmask = nullptr; p.nwhich = 1; p.a_drop.thr16 = 0; p.drop.thr16 = 0; p.next_drop.thr16 = 0; p.kchunk = 0;
+    p.ln_a = nullptr; p.stats = nullptr;
+    return p;
+}
+__device__ __forceinline__ RowGemmParams role_lnbwd(RowGemmParams p) {          // input gradient + LayerNorm backward + residual gradient (bf16 A when it comes from memory)
+    p.a_bf16 = 1; p.A_out = nullptr; p.a_drop.thr16 = 0; p.drop.thr16 = 0; p.bias = nullptr; p.ln_b = nullptr; p.stats = nullptr;
     return p;
 }
 __device__ __forceinline__ RowGemmParams role_bwd_relu(RowGemmParams p) {       // dh = (drop'(g) W) * relu'(hid): bf16 out, copy of the A tile
@@ -767,7 +780,7 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
     rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X, DEVSEED>(role_plain(ch.a), sm);
     rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2, DEVSEED>(role_ffn1(ch.b), sm);
     rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X, DEVSEED>(role_plain(ch.c), sm);
-    rowgemm_stage<EPI_FRAG, true, ASRC_X, 0, false>(ch.d, sm);
+    rowgemm_stage<EPI_FRAG, true, ASRC_X, 0, false>(role_qkv(ch.d), sm);
 }
 
 // Backward, from the layer-output gradient dx2 down to the attention core's operands:
@@ -780,8 +793,8 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
     const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
     rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_A2, DEVSEED>(role_bwd_relu(ch.a), sm);
-    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(ch.b, sm);      // dx1 -> global (fp32) and, as the next A tile, LDS (bf16)
-    rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(ch.c, sm);
+    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(role_lnbwd(ch.b), sm);      // dx1 -> global (fp32) and, as the next A tile, LDS (bf16)
+    rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(role_dO(ch.c), sm);
 }
 
 
@@ -796,8 +809,8 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP); warm_weights(ch.d.W, ch.d.NP, ch.d.KP);
-    rowgemm_stage<EPI_LNBWD, false, ASRC_GLOBAL, KEEP_AS, DEVSEED, WIDE>(ch.a, sm);        // layer l:   dx -> global (fp32) + next A tile (bf16, dropped)
+    rowgemm_stage<EPI_LNBWD, false, ASRC_GLOBAL, KEEP_AS, DEVSEED, WIDE>(role_lnbwd(ch.a), sm);        // layer l:   dx -> global (fp32) + next A tile (bf16, dropped)
     rowgemm_stage<EPI_PLAIN, false, ASRC_AS, KEEP_A2, DEVSEED>(role_bwd_relu(ch.b), sm);                     // layer l-1: dh
-    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(ch.c, sm);                              //            dx1
-    rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(ch.d, sm);                                  //            dO fragments + delta
+    rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(role_lnbwd(ch.c), sm);                              //            dx1
+    rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(role_dO(ch.d), sm);                                  //            dO fragments + delta
 }
