@@ -125,7 +125,44 @@ def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
-SIDE_LANES = {}       # raw stream handle -> lane id (>= 1); filled by multiTransformer._ModalityStreams
+SIDE_LANES = {}       # raw stream handle -> lane id (>= 1); filled by StreamFork
+
+
+class StreamFork:
+    """n independent pieces of work on n HIP streams (the first on the caller's stream), forked and joined by event
+    (``wait_stream``), which is also legal inside hipGraph capture; autograd replays each backward node on the stream of its
+    forward.  Every side stream owns a workspace lane (see WorkspacePool).  Users: the modalities of the MFT / of the window
+    encoder (independent until the MFN gate / the fusion layer) and the sub-batches of one encoder stack (functional.encoder_stack)."""
+
+    def __init__(self, env_switch=None):
+        self._side = {}
+        self._env = env_switch
+
+    def begin(self, device, n):
+        main = torch.cuda.current_stream(device)
+        if n < 2 or (self._env and os.environ.get(self._env, "1") == "0"):
+            return main, [main] * n
+        side = self._side.setdefault(str(device), [])
+        while len(side) < n - 1:
+            side.append(torch.cuda.Stream(device=device))
+            SIDE_LANES[int(side[-1].cuda_stream)] = len(SIDE_LANES) + 1       # own workspace lane (see WorkspacePool)
+        streams = [main] + side[:n - 1]
+        for s in streams[1:]:
+            s.wait_stream(main)
+        return main, streams
+
+    @staticmethod
+    def end(main, streams, tensors=()):
+        for s in set(streams):
+            if s is not main:
+                main.wait_stream(s)
+        for t in tensors:
+            t.record_stream(main)
+
+
+def on_side_lane(device):
+    """True while the current stream is one of StreamFork's side streams (work that is already one of several concurrent pieces)."""
+    return int(torch.cuda.current_stream(device).cuda_stream) in SIDE_LANES
 
 
 class WorkspacePool:
@@ -307,7 +344,7 @@ def _host_seed(device, site):
     return mix64(base, off, rank, site)
 
 
-def next_dropout_seed(device, site, holder=None):
+def next_dropout_seed(device, site, holder=None, index=0):
     """Seed of one train-mode forward of one module.
 
     Eager launches: a python int drawn, like torch's own dropout kernels, from the DEVICE generator (seed, offset), advancing the offset:
@@ -321,19 +358,22 @@ def next_dropout_seed(device, site, holder=None):
     if os.environ.get("MMT_DEVICE_SEED") == "0":         # developer switch: by-value seeds even under capture (frozen at capture, as in round 2)
         holder = None
     if holder is not None:
-        ds = holder.__dict__.get("_dev_seed")
+        seeds = holder.__dict__.setdefault("_dev_seeds", {})      # one state per concurrent piece (`index`: sub-batch stream) of the module
+        ds = seeds.get(index)
         if ds is None or ds.state.device != device:
             if capturing:
                 raise RuntimeError("hipGraph capture of a train-mode %s before its first eager call: run one warm-up step so that its "
                                    "device-resident dropout seed exists" % type(holder).__name__)
-            ds = DeviceSeed(device, _host_seed(device, site))
-            holder.__dict__["_dev_seed"] = ds
+            ds = DeviceSeed(device, _host_seed(device, mix64(site, index)))
+            seeds[index] = ds
+            if index == 0:
+                holder.__dict__["_dev_seed"] = ds
         if capturing or os.environ.get("MMT_DEVICE_SEED") == "1":
             return ds
     elif capturing:
         _seed_fallback_counter[0] += 1
         return mix64(torch.initial_seed(), (1 << 40) + _seed_fallback_counter[0], site)     # frozen under replay: stand-alone attention() only
-    return _host_seed(device, site)
+    return _host_seed(device, mix64(site, index) if index else site)
 
 
 def profile(on):

@@ -22,9 +22,36 @@ def _f32c16(t):
     return t.clone() if t is not None and t.data_ptr() % 16 else t
 
 
+# Sub-batch streams.  Sequences are independent, so one stack call may run as k sub-batches on k HIP streams (forked and joined by event,
+# inside one hipGraph too).  Every kernel of a stack launches all its workgroups in ONE round at the BASELINE sizes, i.e. a step is a
+# chain of ~34 kernel latencies; with two half-batches in flight the attention kernels (bound by vector issue) of one run beside the row
+# chains (bound by latency) of the other, and one half's tail overlaps the other's head.  Measured at configs[3]: 32 sequences as 2 x 16:
+# -3.5 % step time, 64 as 2 x 32: -11 %; 4 streams were no better than 2.  The pieces use seeds of their own (different dropout masks).
+_SPLIT_STREAMS = _lib.StreamFork()
+
+
+def _row_chunks(B, k):
+    k = max(1, min(int(k), B))
+    base, rem = divmod(B, k)
+    out, lo = [], 0
+    for i in range(k):
+        hi = lo + base + (1 if i < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def _chunk_seed(seed, i):
+    if isinstance(seed, (list, tuple)):
+        return seed[i]
+    if i == 0 or isinstance(seed, _lib.DeviceSeed):
+        return seed
+    return _lib.mix64(seed, i)
+
+
 class _EncoderStackFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, mask, flat_params, h, d_ff, n_layers, eps, dropout_p, seed, _needs=False):
+    def forward(ctx, x, mask, flat_params, h, d_ff, n_layers, eps, dropout_p, seed, _needs=False, nsplit=1):
         lib = _lib.load()
         _lib.require_hip(x, mask, flat_params)
         x_, m_, p_ = _f32c(x), _f32c(mask), _f32c(flat_params)
@@ -35,56 +62,82 @@ class _EncoderStackFn(torch.autograd.Function):
         if p_.numel() != need:
             raise ValueError("flat parameter buffer has %d elements, expected %d" % (p_.numel(), need))
         train = dropout_p > 0.0                    # eval-mode workspaces carry no dropout bit masks
-        nbytes = (lib.mmt_encoder_workspace_bytes if train else lib.mmt_encoder_workspace_bytes_eval)(B, T, d, h, d_ff, n_layers)
-        if nbytes == 0:
-            _lib.check(lib.mmt_encoder_forward(None, None, None, None, None, 0, B, T, d, h, d_ff, n_layers, eps, 0.0, 0, None))
-        ws = _lib.POOL.get(nbytes, x_.device, tag=("encoder", B, T, d, h, d_ff, n_layers, train))
+        if isinstance(seed, (list, tuple)) and len(seed) < nsplit:
+            raise ValueError("encoder_stack: one seed per sub-batch stream")
         y = torch.empty_like(x_)
-        if isinstance(seed, _lib.DeviceSeed):        # device-resident seed: read and advanced by the launch itself (hipGraph replays)
-            _lib.check(lib.mmt_encoder_forward_devseed(_lib.ptr(x_), _lib.ptr(m_), _lib.ptr(p_), _lib.ptr(y), _lib.ptr(ws), nbytes,
-                                                       B, T, d, h, d_ff, n_layers, eps, dropout_p, seed.ptr(), _lib.stream_ptr()))
-        else:
-            _lib.check(lib.mmt_encoder_forward(_lib.ptr(x_), _lib.ptr(m_), _lib.ptr(p_), _lib.ptr(y), _lib.ptr(ws), nbytes,
-                                               B, T, d, h, d_ff, n_layers, eps, dropout_p, seed, _lib.stream_ptr()))
+        chunks = _row_chunks(B, nsplit)
+        main, streams = _SPLIT_STREAMS.begin(x_.device, len(chunks))
+        parts = []
+        for i, ((b0, b1), st) in enumerate(zip(chunks, streams)):
+            with torch.cuda.stream(st):
+                Bi = b1 - b0
+                nbytes = (lib.mmt_encoder_workspace_bytes if train else lib.mmt_encoder_workspace_bytes_eval)(Bi, T, d, h, d_ff, n_layers)
+                if nbytes == 0:
+                    _lib.check(lib.mmt_encoder_forward(None, None, None, None, None, 0, Bi, T, d, h, d_ff, n_layers, eps, 0.0, 0, None))
+                ws = _lib.POOL.get(nbytes, x_.device, tag=("encoder", Bi, T, d, h, d_ff, n_layers, train))
+                sd = _chunk_seed(seed, i)
+                xp, mp, yp = _lib.ptr(x_) + 4 * b0 * T * d, _lib.ptr(m_) + 4 * b0 * T, _lib.ptr(y) + 4 * b0 * T * d
+                if isinstance(sd, _lib.DeviceSeed):  # device-resident seed: read and advanced by the launch itself (hipGraph replays)
+                    _lib.check(lib.mmt_encoder_forward_devseed(xp, mp, _lib.ptr(p_), yp, _lib.ptr(ws), nbytes,
+                                                               Bi, T, d, h, d_ff, n_layers, eps, dropout_p, sd.ptr(), _lib.stream_ptr()))
+                else:
+                    _lib.check(lib.mmt_encoder_forward(xp, mp, _lib.ptr(p_), yp, _lib.ptr(ws), nbytes,
+                                                       Bi, T, d, h, d_ff, n_layers, eps, dropout_p, sd, _lib.stream_ptr()))
+                parts.append((b0, b1, ws, nbytes, sd))
+        _SPLIT_STREAMS.end(main, streams)
         needs_bwd = _needs or any(ctx.needs_input_grad)
         if needs_bwd:
             ctx.save_for_backward(x_, m_, p_)
-            ctx.ws = ws
-            ctx.cfg = (B, T, d, h, d_ff, n_layers, eps, dropout_p, seed, nbytes)
+            ctx.parts = parts
+            ctx.cfg = (B, T, d, h, d_ff, n_layers, eps, dropout_p)
         else:
-            _lib.POOL.put(ws)
+            for part in parts:
+                _lib.POOL.put(part[2])
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
         x_, m_, p_ = ctx.saved_tensors
-        B, T, d, h, d_ff, n_layers, eps, dropout_p, seed, nbytes = ctx.cfg
-        if ctx.ws is None:
+        B, T, d, h, d_ff, n_layers, eps, dropout_p = ctx.cfg
+        if ctx.parts is None:
             raise RuntimeError("encoder_stack: backward called twice on the same forward (workspace already released)")
+        parts, ctx.parts = ctx.parts, None
         dy_ = _f32c(dy)
         dx = torch.empty_like(x_)
-        dp = torch.empty_like(p_)           # fresh buffer per call: returned gradient views never alias later calls
-        if isinstance(seed, _lib.DeviceSeed):        # the forward left its seed in the workspace
-            _lib.check(lib.mmt_encoder_backward_devseed(_lib.ptr(dy_), _lib.ptr(x_), _lib.ptr(m_), _lib.ptr(p_), _lib.ptr(dx), _lib.ptr(dp),
-                                                        _lib.ptr(ctx.ws), nbytes, B, T, d, h, d_ff, n_layers, eps, dropout_p,
-                                                        _lib.stream_ptr()))
-        else:
-            _lib.check(lib.mmt_encoder_backward(_lib.ptr(dy_), _lib.ptr(x_), _lib.ptr(m_), _lib.ptr(p_), _lib.ptr(dx), _lib.ptr(dp),
-                                                _lib.ptr(ctx.ws), nbytes, B, T, d, h, d_ff, n_layers, eps, dropout_p, seed,
-                                                _lib.stream_ptr()))
-        _lib.POOL.put(ctx.ws)
-        ctx.ws = None
-        return dx, None, dp, None, None, None, None, None, None
+        dps = [torch.empty_like(p_) for _ in parts]     # fresh buffers per call: returned gradient views never alias later calls
+        main, streams = _SPLIT_STREAMS.begin(x_.device, len(parts))
+        for (b0, b1, ws, nbytes, sd), dp, st in zip(parts, dps, streams):
+            with torch.cuda.stream(st):
+                Bi = b1 - b0
+                gp, xp, mp, dxp = (_lib.ptr(dy_) + 4 * b0 * T * d, _lib.ptr(x_) + 4 * b0 * T * d, _lib.ptr(m_) + 4 * b0 * T,
+                                   _lib.ptr(dx) + 4 * b0 * T * d)
+                if isinstance(sd, _lib.DeviceSeed):  # the forward left its seed in the workspace
+                    _lib.check(lib.mmt_encoder_backward_devseed(gp, xp, mp, _lib.ptr(p_), dxp, _lib.ptr(dp), _lib.ptr(ws), nbytes,
+                                                                Bi, T, d, h, d_ff, n_layers, eps, dropout_p, _lib.stream_ptr()))
+                else:
+                    _lib.check(lib.mmt_encoder_backward(gp, xp, mp, _lib.ptr(p_), dxp, _lib.ptr(dp), _lib.ptr(ws), nbytes,
+                                                        Bi, T, d, h, d_ff, n_layers, eps, dropout_p, sd, _lib.stream_ptr()))
+                _lib.POOL.put(ws)
+        _SPLIT_STREAMS.end(main, streams)
+        if len(dps) > 1:                                # the sub-batches' parameter gradients, summed into the first buffer
+            n = p_.numel()
+            for other in dps[1:]:
+                copy2d([_seg(dps[0], n, 1, n, src=other, src_ld=n, acc=True)])
+        return dx, None, dps[0], None, None, None, None, None, None, None, None
 
 
 def _seed_arg(seed):
+    if isinstance(seed, (list, tuple)):
+        return [_seed_arg(v) for v in seed]
     return seed if isinstance(seed, _lib.DeviceSeed) else int(seed)
 
 
-def encoder_stack(x, mask, flat_params, h, d_ff, n_layers, eps=1e-6, dropout_p=0.0, seed=0):
-    """``seed``: a python int (by value) or a ``_lib.DeviceSeed`` (device-resident: fresh masks at every hipGraph replay)."""
-    return _EncoderStackFn.apply(x, mask, flat_params, int(h), int(d_ff), int(n_layers), float(eps), float(dropout_p), _seed_arg(seed))
+def encoder_stack(x, mask, flat_params, h, d_ff, n_layers, eps=1e-6, dropout_p=0.0, seed=0, nsplit=1):
+    """``seed``: a python int (by value) or a ``_lib.DeviceSeed`` (device-resident: fresh masks at every hipGraph replay), or one
+    of either per sub-batch stream; ``nsplit``: run the batch as that many sub-batches on HIP streams of their own (see _SPLIT_STREAMS)."""
+    return _EncoderStackFn.apply(x, mask, flat_params, int(h), int(d_ff), int(n_layers), float(eps), float(dropout_p), _seed_arg(seed),
+                                 False, int(nsplit))
 
 
 class _EncoderStackParamsFn(torch.autograd.Function):
@@ -94,14 +147,15 @@ class _EncoderStackParamsFn(torch.autograd.Function):
     buffer in place with one collective and no staging copies (``parallel.allreduce_gradients``)."""
 
     @staticmethod
-    def forward(ctx, x, mask, h, d_ff, n_layers, eps, dropout_p, seed, flat, *params):
+    def forward(ctx, x, mask, h, d_ff, n_layers, eps, dropout_p, seed, flat, nsplit, *params):
         # `flat`: the parameters' own storage when they are views of one buffer (multiTransformer.Encoder keeps them that way), else
         # None and the buffer is assembled here (one concatenation kernel per step)
         if flat is None:
             flat = torch.cat([q.detach().reshape(-1) for q in params]).float()
         ctx.shapes = [tuple(q.shape) for q in params]
         ctx.inner = _Ctx()
-        y = _EncoderStackFn.forward(ctx.inner, x, mask, flat, h, d_ff, n_layers, eps, dropout_p, seed, _needs=any(ctx.needs_input_grad))
+        y = _EncoderStackFn.forward(ctx.inner, x, mask, flat, h, d_ff, n_layers, eps, dropout_p, seed, _needs=any(ctx.needs_input_grad),
+                                    nsplit=nsplit)
         return y
 
     @staticmethod
@@ -114,7 +168,7 @@ class _EncoderStackParamsFn(torch.autograd.Function):
                 n *= v
             grads.append(dflat[off:off + n].view(shp))
             off += n
-        return (dx, None, None, None, None, None, None, None, None) + tuple(grads)
+        return (dx, None, None, None, None, None, None, None, None, None) + tuple(grads)
 
 
 class _Ctx:
@@ -125,8 +179,9 @@ class _Ctx:
         self.saved_tensors = t
 
 
-def encoder_stack_params(x, mask, params, h, d_ff, n_layers, eps=1e-6, dropout_p=0.0, seed=0, flat=None):
-    return _EncoderStackParamsFn.apply(x, mask, int(h), int(d_ff), int(n_layers), float(eps), float(dropout_p), _seed_arg(seed), flat, *params)
+def encoder_stack_params(x, mask, params, h, d_ff, n_layers, eps=1e-6, dropout_p=0.0, seed=0, flat=None, nsplit=1):
+    return _EncoderStackParamsFn.apply(x, mask, int(h), int(d_ff), int(n_layers), float(eps), float(dropout_p), _seed_arg(seed), flat,
+                                       int(nsplit), *params)
 
 
 class _LayerNormFn(torch.autograd.Function):

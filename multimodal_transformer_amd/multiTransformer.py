@@ -216,11 +216,25 @@ class Encoder(nn.Module):
             return self.norm(x)
         l0 = self.layers[0]
         p = l0.sublayer[0].dropout.p if self.training else 0.0
-        seed = _lib.next_dropout_seed(x.device, 1, holder=self) if p > 0.0 else 0
+        k = self._sub_batch_streams(x)
+        seed = [_lib.next_dropout_seed(x.device, 1, holder=self, index=i) for i in range(k)] if p > 0.0 else 0
         ps = self.flat_parameters()
         return F_hip.encoder_stack_params(x, mask, ps, l0.self_attn.h, l0.feed_forward.w_1.weight.shape[0],
                                           len(self.layers), eps=self.norm.eps, dropout_p=p, seed=seed,
-                                          flat=self._flat_storage(ps) if x.is_cuda else None)
+                                          flat=self._flat_storage(ps) if x.is_cuda else None, nsplit=k)
+
+    sub_batch_streams = 1        # set to 2: the batch runs as two halves on two HIP streams (functional._SPLIT_STREAMS); opt-in
+    sub_batch_min_windows = 8192
+
+    def _sub_batch_streams(self, x):
+        """``sub_batch_streams`` sub-batches on streams of their own when the call is large enough for it to pay (>= 8192 windows:
+        every BASELINE configuration) and is not itself one of several concurrent pieces (a modality of the MFT).  Off by default:
+        -3.5 % step time at configs[3]'s 32 sequences, -11 % at 64, but the halves draw dropout masks of their own and per-kernel
+        timings (bench.py's roofline) are no longer those of a kernel that has the GPU to itself."""
+        k = int(os.environ.get("MMT_ENCODER_STREAMS", self.sub_batch_streams))
+        if not x.is_cuda or k < 2 or x.shape[0] < 2 or x.shape[0] * x.shape[1] < self.sub_batch_min_windows or _lib.on_side_lane(x.device):
+            return 1
+        return min(k, x.shape[0])
 
 
 def _encoder(embed_dim, h, d_ff, dropout, N):
@@ -228,39 +242,10 @@ def _encoder(embed_dim, h, d_ff, dropout, N):
                                 dropout), N)
 
 
-class _ModalityStreams:
-    """The modalities of the MFT are independent until the MFN gate: their embeds, encoder stacks and LSTM scans
-    run on one HIP stream each (the first on the caller's stream).  One stack at the reference sizes fills only part
-    of the 256 CUs (B*T/32 workgroups of four waves), so concurrency, not a faster kernel, is what is missing.
-    Fork/join is by event (``wait_stream``), which is also legal inside hipGraph capture; autograd replays each
-    backward node on the stream of its forward.  ``MMT_MODALITY_STREAMS=0`` serialises everything on one stream."""
-
-    def __init__(self):
-        self._side = {}
-
-    def begin(self, device, n):
-        main = torch.cuda.current_stream(device)
-        if os.environ.get("MMT_MODALITY_STREAMS", "1") == "0" or n < 2:
-            return main, [main] * n
-        side = self._side.setdefault(str(device), [])
-        while len(side) < n - 1:
-            side.append(torch.cuda.Stream(device=device))
-            _lib.SIDE_LANES[int(side[-1].cuda_stream)] = len(_lib.SIDE_LANES) + 1       # own workspace lane (see WorkspacePool)
-        streams = [main] + side[:n - 1]
-        for s in streams[1:]:
-            s.wait_stream(main)
-        return main, streams
-
-    @staticmethod
-    def end(main, streams, tensors):
-        for s in set(streams):
-            if s is not main:
-                main.wait_stream(s)
-        for t in tensors:
-            t.record_stream(main)
-
-
-_MOD_STREAMS = _ModalityStreams()
+# The modalities of the MFT are independent until the MFN gate: their embeds, encoder stacks and LSTM scans run on one HIP stream each
+# (the first on the caller's stream): one stack at the reference sizes fills only part of the 256 CUs, so concurrency, not a faster
+# kernel, is what is missing.  ``MMT_MODALITY_STREAMS=0`` serialises everything on one stream.
+_MOD_STREAMS = _lib.StreamFork("MMT_MODALITY_STREAMS")
 
 
 class MFN(nn.Module):

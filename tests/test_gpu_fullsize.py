@@ -260,3 +260,32 @@ def test_full_size_mft_model_configs4(dev):
     for n, p in live:
         assert torch.isfinite(p.grad).all(), n
     F.check_device_errors()
+
+
+def test_sub_batch_streams_match_single_stream(dev):
+    """Encoder.sub_batch_streams = 2 (the batch as two halves on two HIP streams, parameter gradients of the halves summed): in eval
+    mode outputs and input gradients equal the single-stream run bit for bit (a sequence's result does not depend on its batch) and the
+    parameter gradients to summation order; in train mode the step runs and every gradient is finite."""
+    cfg = FULL["C4"]
+    B, T, d = cfg["B"], cfg["T"], cfg["d"]
+    enc, _ = _encoder(cfg, dev, 5)
+    lengths = _lengths(B, T)
+    mask = R.prefix_mask(lengths, T).to(dev)
+    x = R.gen_normal("split:x", (B, T, d), 5).to(dev)
+    g = (R.gen_normal("split:g", (B, T, d), 5) * R.prefix_mask(lengths, T)).to(dev)
+    y1, dx1, gw1 = _run(enc, x, mask, g)
+    enc.sub_batch_streams = 2
+    try:
+        assert enc._sub_batch_streams(x) == 2
+        y2, dx2, gw2 = _run(enc, x, mask, g)
+        assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
+        assert rel_l2(gw2.cpu().numpy(), gw1.cpu().numpy()) < 1e-4
+        assert all(p.grad.untyped_storage().data_ptr() == enc.layers[0].self_attn.linears[0].weight.grad.untyped_storage().data_ptr()
+                   for p in enc.flat_parameters())                       # still views of ONE flat gradient buffer
+        enc.train()
+        y3, dx3, gw3 = _run(enc, x, mask, g)
+        assert torch.isfinite(y3).all() and torch.isfinite(dx3).all() and torch.isfinite(gw3).all()
+        assert float((y3 - y2).abs().max()) > 1e-2                        # dropout happened
+    finally:
+        enc.sub_batch_streams = 1
+        enc.eval()
