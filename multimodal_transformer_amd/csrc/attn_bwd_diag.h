@@ -61,6 +61,10 @@ __global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
         int h, int T, int nt, const uint16_t* __restrict__ maskK, float drop_scale) {
     constexpr int DKP = 16, RT = MMT_DIAG_RT_PIECES, TOTAL = MMT_DIAG_QD_PIECES, NW = MMT_DIAG_NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef MMT_ABLATIONS
+    unsigned long long st_kernel = 0;
+    if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_kernel) :: "memory");
+#endif
     bf16* const qd0 = reinterpret_cast<bf16*>(smem);                                    // [NW][TOTAL * 8] bf16: every query tile of the head
     const bf16* const zeros = reinterpret_cast<const bf16*>(smem + NW * TOTAL * 16);    // what the padding feature rows of an A fragment read
     char* const kvl0 = smem + NW * TOTAL * 16 + MMT_DIAG_ZERO_BYTES;                    // [NW][2][RT * 16]: own K and V tiles (R layout, padded groups)
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
         unsigned long long* q = g_attn_stamps + ((size_t)blockIdx.x * NW + wave) * 16;
         for (int i = 0; i < 7; ++i) q[i] = st_acc[i];
-        q[7] = t1 - st_entry; q[9] = live ? 1 : 2;
+        q[7] = t1 - st_entry; q[9] = live ? 1 : 2; q[10] = st_entry - st_kernel; q[14] = t1;
     }
 #endif
     lds_barrier();                                      // every accumulator is complete
@@ -300,4 +304,11 @@ __global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
             *reinterpret_cast<bf16x4*>(dqkv + m * lddkv + 2 * HD + e0) = vv;
         }
     }
+#ifdef MMT_ABLATIONS
+    if (STAMP && g_attn_stamps && lane == 0) {          // kernel exit, stores retired
+        unsigned long long t2;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2) :: "memory");
+        g_attn_stamps[((size_t)blockIdx.x * NW + wave) * 16 + 15] = t2;
+    }
+#endif
 }

@@ -41,15 +41,9 @@ print("live waves %d: lifetime median %.0f cycles (min %.0f max %.0f) = %.0f per
 tot = live[:, :7].sum()
 for i, nm in enumerate(SEG):
     print("  %-56s %6.0f cycles/tile  %5.1f %%" % (nm, live[:, i].mean() / 16, 100 * live[:, i].sum() / tot))
-# launch skew, prologue, sweep, epilogue per workgroup (absolute s_memtime stamps: q[12] kernel entry, q[14] sweep end, q[15] exit)
+# prologue (kernel entry -> first step), sweep, epilogue (last step -> stores retired) per workgroup; s_memtime bases differ between XCDs,
+# so only differences inside one workgroup are formed
 wg = full.reshape(B * h, 16, 16)
-last = stamps.cpu().numpy().reshape(-1, B * h, 16, 16)[-1] if False else wg
-entry = wg[:, :, 12].min(axis=1); sweep0 = (wg[:, :, 12] + wg[:, :, 10]).max(axis=1); sweep1 = wg[:, :, 14].max(axis=1); exit_ = wg[:, :, 15].max(axis=1)
-t0 = entry.min()
-print("per workgroup (cycles): entry skew median %.0f max %.0f | prologue median %.0f | sweep median %.0f (min %.0f max %.0f) | epilogue median %.0f | exit: median %.0f max %.0f after the first entry"
-      % (np.median(entry - t0), (entry - t0).max(), np.median(sweep0 - entry), np.median(sweep1 - sweep0), (sweep1 - sweep0).min(), (sweep1 - sweep0).max(),
-         np.median(exit_ - sweep1), np.median(exit_ - t0), (exit_ - t0).max()))
-xcd = np.arange(B * h) % 8
-for x8 in range(8):
-    m = xcd == x8
-    print("  XCD %d: entry %.0f..%.0f  sweep median %.0f  exit max %.0f" % (x8, (entry[m] - t0).min(), (entry[m] - t0).max(), np.median((sweep1 - sweep0)[m]), (exit_[m] - t0).max()))
+pro = wg[:, :, 10].max(axis=1); swp = wg[:, :, 7].max(axis=1); epi = (wg[:, :, 15] - wg[:, :, 14]).max(axis=1)
+print("per workgroup, cycles: prologue median %.0f (max %.0f) | sweep median %.0f (min %.0f max %.0f) | epilogue median %.0f (max %.0f) | sum %.0f"
+      % (np.median(pro), pro.max(), np.median(swp), swp.min(), swp.max(), np.median(epi), epi.max(), np.median(pro + swp + epi)))
