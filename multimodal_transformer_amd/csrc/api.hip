@@ -1228,13 +1228,19 @@ extern "C" int mmt_lstm_scan_forward(const float* gx, const float* W_rec, const 
         hipLaunchKernelGGL((lstm_scan_fwd256_kernel<4, 1>), dim3(B), dim3(64 * ((W.HP16 + 31) / 32)), 0, st,
                            gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16);
     } else if (BT <= 2) {       // cooperative step-input loader (see scan.h)
-        if (W.HPAD == 64) MMT_LSTM_FWD(2, 256, true, 4, true);
-        else if (W.HPAD == 128) MMT_LSTM_FWD(4, 512, true, 4, true);
-        else MMT_LSTM_FWD(8, 1024, false, 1, true);
+        if (BT == 1) {
+            if (W.HPAD == 64) MMT_LSTM_FWD(2, 256, true, 4, 1);
+            else if (W.HPAD == 128) MMT_LSTM_FWD(4, 512, true, 4, 1);
+            else MMT_LSTM_FWD(8, 1024, false, 1, 1);
+        } else {
+            if (W.HPAD == 64) MMT_LSTM_FWD(2, 256, true, 4, 2);
+            else if (W.HPAD == 128) MMT_LSTM_FWD(4, 512, true, 4, 2);
+            else MMT_LSTM_FWD(8, 1024, false, 1, 2);
+        }
     } else {
-        if (W.HPAD == 64) MMT_LSTM_FWD(2, 256, true, 4, false);
-        else if (W.HPAD == 128) MMT_LSTM_FWD(4, 512, true, 2, false);
-        else MMT_LSTM_FWD(8, 1024, false, 1, false);
+        if (W.HPAD == 64) MMT_LSTM_FWD(2, 256, true, 4, 0);
+        else if (W.HPAD == 128) MMT_LSTM_FWD(4, 512, true, 2, 0);
+        else MMT_LSTM_FWD(8, 1024, false, 1, 0);
     }
 #undef MMT_LSTM_FWD
     LAUNCH_CHECK("lstm_scan_fwd_kernel");
@@ -1258,8 +1264,9 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
     const size_t lds = (size_t)2 * 16 * (4 * W.HPAD + 8) * 2 + (coop ? ((size_t)2 * 2 * 8 * W.HPAD + 64 * (W.HP16 / 16)) * sizeof(float) : 0);
     static bool attr = false;
     if (!attr) {
-        if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false, 1, false>))) return rc;
-        if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false, 2, true>))) return rc;
+        if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false, 1, 0>))) return rc;
+        if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false, 2, 1>))) return rc;
+        if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false, 2, 2>))) return rc;
         attr = true;
     }
     ProfScope prof(S_LSTM_BWD, st);
@@ -1283,13 +1290,19 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
         hipLaunchKernelGGL((lstm_scan_bwd256_kernel<16, 1>), dim3(B), dim3(64 * ((W.HP16 + 31) / 32)), lds256, st,
                            dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16);
     } else if (coop) {
-        if (W.HPAD == 64) MMT_LSTM_BWD(8, 256, true, 4, true);
-        else if (W.HPAD == 128) MMT_LSTM_BWD(16, 512, true, 4, true);
-        else MMT_LSTM_BWD(32, 1024, false, 2, true);
+        if (BT == 1) {
+            if (W.HPAD == 64) MMT_LSTM_BWD(8, 256, true, 4, 1);
+            else if (W.HPAD == 128) MMT_LSTM_BWD(16, 512, true, 4, 1);
+            else MMT_LSTM_BWD(32, 1024, false, 2, 1);
+        } else {
+            if (W.HPAD == 64) MMT_LSTM_BWD(8, 256, true, 4, 2);
+            else if (W.HPAD == 128) MMT_LSTM_BWD(16, 512, true, 4, 2);
+            else MMT_LSTM_BWD(32, 1024, false, 2, 2);
+        }
     } else {
-        if (W.HPAD == 64) MMT_LSTM_BWD(8, 256, true, 2, false);
-        else if (W.HPAD == 128) MMT_LSTM_BWD(16, 512, true, 2, false);
-        else MMT_LSTM_BWD(32, 1024, false, 1, false);
+        if (W.HPAD == 64) MMT_LSTM_BWD(8, 256, true, 2, 0);
+        else if (W.HPAD == 128) MMT_LSTM_BWD(16, 512, true, 2, 0);
+        else MMT_LSTM_BWD(32, 1024, false, 1, 0);
     }
 #undef MMT_LSTM_BWD
     LAUNCH_CHECK("lstm_scan_bwd_kernel");

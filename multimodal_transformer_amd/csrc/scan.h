@@ -42,7 +42,14 @@ __global__ void lstm_prep_kernel(const float* __restrict__ W, bf16* __restrict__
 // chunk per thread, PF steps ahead through a register ring and then a two-slot LDS ring.  With one or two live MFMA
 // columns a per-lane prefetch would park 16-32 VGPRs per step in flight in every lane for four useful lanes per wave,
 // which limits the depth to ~2 steps — less than the L2/MALL latency of the loads (measured: 1.6 of 2.1 us per step).
-template <int KS, int NT, bool WREG, int PF, bool COOP>
+// COOP = the workgroup's sequence count (1 or 2; 0: the general form).  The cooperative form also swaps the MFMA operands: the
+// product is h W^T (A = the h rows, B = the wave's W_rec rows), so the accumulator holds sequence 4*(lane>>4) + register and hidden
+// unit lane & 15 — the one or two live sequences are registers 0 / 1 of lanes 0..15, every live lane owns ONE hidden unit, and the
+// gate math runs on those registers directly.  (The other way round — units in the registers, the sequence on the lane — four
+// lanes of a wave hold 16 pre-activations each: either ten transcendentals per unit issue for four useful lanes, or the
+// accumulators go through an LDS patch to be re-dealt one unit per lane, which was a write, a wait and four reads on every step's
+// critical path.)
+template <int KS, int NT, bool WREG, int PF, int COOP>
 __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restrict__ gx, const bf16* __restrict__ Wf,
                                      const float* __restrict__ h0, const float* __restrict__ c0,
                                      float* __restrict__ h_all, float* __restrict__ c_all, float* __restrict__ acts,
@@ -67,22 +74,23 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
     }
     for (int i = threadIdx.x; i < 2 * 16 * ldh; i += blockDim.x) hbuf[i] = (bf16)0.f;
     __syncthreads();
-    // COOP: "dense" gate math.  With nb <= 2 live MFMA columns only 4-8 lanes of a wave hold gate pre-activations, yet the
-    // ten transcendentals per hidden unit would issue for all 64 (2 x 640 quarter-rate cycles per SIMD and step — half of
-    // the step).  The accumulators are therefore re-dealt through a wave-private LDS patch so that lane (ds = lane>>4,
-    // du = lane&15) owns exactly one (sequence, hidden unit) pair; cell state, outputs and stores follow that layout.
-    __shared__ __attribute__((aligned(16))) float xch[COOP ? (NT / 64) * 256 : 4];      // per wave [gate][4 seq][16 units]
+    // COOP: lane (lq == 0, l15) owns hidden unit ud of the workgroup's NR sequences (registers 0 .. NR-1 of its accumulators)
+    constexpr int NR = COOP ? COOP : 1;
     const int nb = (B - (int)blockIdx.x * BT) < BT ? (B - (int)blockIdx.x * BT) : BT;
-    const int ds = lane >> 4, du = lane & 15, ud = jt * 16 + du;
-    const int bd = blockIdx.x * BT + ds;
-    const bool lived = COOP && (ds < nb) && (ud < H);
-    float cd = 0.f;
+    const int ud = jt * 16 + l15, udc = ud < H ? ud : H - 1;
+    const int bd0 = blockIdx.x * BT;
+    const bool ulive = COOP && (lq == 0) && (ud < H);
+    float cd[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) cd[r] = 0.f;
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
     if (COOP) {
-        if (lived) {
-            if (c0) cd = c0[(size_t)bd * H + ud];
-            if (h0) hbuf[ds * ldh + ud] = (bf16)h0[(size_t)bd * H + ud];
-        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (ulive && r < nb) {
+                if (c0) cd[r] = c0[(size_t)(bd0 + r) * H + ud];
+                if (h0) hbuf[r * ldh + ud] = (bf16)h0[(size_t)(bd0 + r) * H + ud];
+            }
     } else if (live) {
         if (c0) c = *reinterpret_cast<const f32x4*>(c0 + (size_t)b * H + j0);
         if (h0) {
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
     const int cb = ld_on ? (int)threadIdx.x / H : 0, co = ld_on ? 4 * ((int)threadIdx.x % H) : 0;
     const float* gxl = COOP ? gx + ((size_t)(blockIdx.x * BT + cb) * 4 * H + co) : gx + (size_t)bc * 4 * H + jc;   // + t*gstep (+ q*H)
     const int lds_dst = cb * 4 * H + co;
-    const int lds_src = (ds < nb ? ds : 0) * 4 * H + (ud < H ? ud : H - 1);      // dense lane's scalar of each gate
+    const int lds_src = udc;                                    // + r*4H + q*H: this lane's unit, gate q of sequence r
     auto fetch = [&](f32x4 (&r)[RW], int t) {
         const int tl = t < T ? t : T - 1;                       // clamped: the tail re-reads the last step (unused)
 #pragma unroll
@@ -124,11 +132,15 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
     int cur = 0;
     auto step = [&](int t, f32x4 (&in)[RW]) {
         f32x4 acc[4];
-        float gin[4];
+        float gin[NR][4];
         if (COOP) {
             const float* sl = gslot + (t & 1) * SLOT + lds_src;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { gin[q] = sl[q * H]; acc[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int q = 0; q < 4; ++q) {
+                acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < NR; ++r) gin[r][q] = sl[(r < nb ? r : 0) * 4 * H + q * H];
+            }
             // hand step t+1's chunk to the other slot (its readers finished before the previous barrier), refill the ring
             if (ld_on) *reinterpret_cast<f32x4*>(gslot + ((t + 1) & 1) * SLOT + lds_dst) = in[0];
             fetch(in, t + 1 + PF);
@@ -143,7 +155,8 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 bf = *reinterpret_cast<const bf16x8*>(hb + ks * 32);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = mfma16(a[WREG ? q : 0][WREG ? ks : 0], bf, acc[q]);
+                for (int q = 0; q < 4; ++q)
+                    acc[q] = COOP ? mfma16(bf, a[WREG ? q : 0][WREG ? ks : 0], acc[q]) : mfma16(a[WREG ? q : 0][WREG ? ks : 0], bf, acc[q]);
             }
         } else {
             // streamed weights: two k-blocks of fragments in flight; the scheduling fences keep hipcc from hoisting
@@ -159,30 +172,31 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
                 }
                 const bf16x8 bf = *reinterpret_cast<const bf16x8*>(hb + ks * 32);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = mfma16(wa[ks & 1][q], bf, acc[q]);
+                for (int q = 0; q < 4; ++q) acc[q] = COOP ? mfma16(bf, wa[ks & 1][q], acc[q]) : mfma16(wa[ks & 1][q], bf, acc[q]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (COOP) {
-            float* xw = xch + jt * 256;
-            if (l15 < 4) {
+            float ig[NR], fg[NR], gg[NR], og[NR], hn[NR];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(xw + (q * 4 + l15) * 16 + 4 * lq) = acc[q];
+            for (int r = 0; r < NR; ++r) {
+                ig[r] = sigmoid_f(acc[0][r] + gin[r][0]); fg[r] = sigmoid_f(acc[1][r] + gin[r][1]);
+                gg[r] = tanh_f(acc[2][r] + gin[r][2]); og[r] = sigmoid_f(acc[3][r] + gin[r][3]);
+                cd[r] = fg[r] * cd[r] + ig[r] * gg[r];
+                hn[r] = og[r] * tanh_f(cd[r]);
+                // rows >= nb and units >= H of the h tile stay 0 (never written); lanes lq != 0 hold products of those zero rows
+                if (ulive && r < nb) hbuf[(cur ^ 1) * 16 * ldh + r * ldh + ud] = (bf16)hn[r];
             }
-            // same-wave LDS traffic is ordered: no barrier between the re-deal's writes and reads
-            const float ig = sigmoid_f(xw[(0 * 4 + ds) * 16 + du] + gin[0]), fg = sigmoid_f(xw[(1 * 4 + ds) * 16 + du] + gin[1]);
-            const float gg = tanh_f(xw[(2 * 4 + ds) * 16 + du] + gin[2]), og = sigmoid_f(xw[(3 * 4 + ds) * 16 + du] + gin[3]);
-            cd = fg * cd + ig * gg;
-            const float hn = lived ? og * tanh_f(cd) : 0.f;     // pad lanes keep h = 0 in LDS
-            hbuf[(cur ^ 1) * 16 * ldh + ds * ldh + ud] = (bf16)hn;
             lds_barrier();                                      // h_t visible to every wave; global traffic stays in flight
-            if (lived) {
-                const size_t o = ((size_t)t * B + bd) * H + ud;
-                h_all[o] = hn;
-                c_all[o] = cd;
-                float* ap = acts + ((size_t)t * B + bd) * 4 * H + ud;
-                ap[0] = ig; ap[H] = fg; ap[2 * H] = gg; ap[3 * H] = og;
-            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (ulive && r < nb) {
+                    const size_t o = ((size_t)t * B + bd0 + r) * H + ud;
+                    h_all[o] = hn[r];
+                    c_all[o] = cd[r];
+                    float* ap = acts + ((size_t)t * B + bd0 + r) * 4 * H + ud;
+                    ap[0] = ig[r]; ap[H] = fg[r]; ap[2 * H] = gg[r]; ap[3 * H] = og[r];
+                }
         } else {
             f32x4 ig, fg, gg, og, hn;
 #pragma unroll
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
 
 // Backward through time.  dG[t] (gate pre-activation gradients, fp32 (T,B,4H)) is also what the batched
 // input-projection / weight gradients consume afterwards.  KS4 = 4*HPAD/32.
-template <int KS4, int NT, bool WREG, int PF, bool COOP>
+template <int KS4, int NT, bool WREG, int PF, int COOP>
 __global__ __launch_bounds__(NT) void lstm_scan_bwd_kernel(const float* __restrict__ dh_ext, const float* __restrict__ dc_ext,
                                      const bf16* __restrict__ Wb, const float* __restrict__ c0,
                                      const float* __restrict__ c_all, const float* __restrict__ acts,
@@ -302,37 +316,59 @@ __global__ __launch_bounds__(NT) void lstm_scan_bwd_kernel(const float* __restri
         for (int d = 0; d < PF; ++d) fetch(ring[d], T - 1 - d);
     }
     int cur = 0;
-    // dense gate math for the cooperative form (see the forward kernel): lane (ds, du) owns one (sequence, unit) pair
-    const int ds = lane >> 4, du = lane & 15, ud = jt * 16 + du;
-    const int bd = blockIdx.x * BT + ds;
-    const bool lived = COOP && (ds < nb) && (ud < H);
-    const float lvd = lived ? 1.f : 0.f;
-    const int dsrc = (ds < nb ? ds : 0) * 8 * H + (ud < H ? ud : H - 1);
-    float* xw = gslot + 2 * SLOT + jt * 64;                     // per-wave re-deal patch [4 seq][16 units]
-    float dhd = 0.f, dcd = 0.f;                                 // dense copies of dh_rec / dc
+    // cooperative form (see the forward kernel): the product is dG W (A = the gate-gradient rows, B = the wave's rows of W^T), so lane
+    // (lq == 0, l15) owns hidden unit ud of the workgroup's NR sequences (registers 0 .. NR-1 of the accumulator)
+    constexpr int NR = COOP ? COOP : 1;
+    const int ud = jt * 16 + l15, bd0 = blockIdx.x * BT;
+    const bool ulive = COOP && (lq == 0) && (ud < H);
+    const int dsrc = ud < H ? ud : H - 1;                       // + r * 8H
+    float dhd[NR], dcd[NR];                                     // dh_rec / dc of the lane's unit
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { dhd[r] = 0.f; dcd[r] = 0.f; }
+    // Everything of a step that does not depend on the recurrence (the saved activations' derivative factors, one tanh) is computed
+    // a step AHEAD, while the MFMAs of the step before run: what stays on the dh -> dgates -> dh chain is six multiply-adds.
+    struct Coef { float a, b, ci, cf, cg, f, dhe, dce; };      // dct = dc + dce + dh a;  dgo = dh b;  dgi/dgf/dgg = dct ci/cf/cg;  dc' = dct f
+    Coef cf[NR];
+    auto coefs = [&](int slot) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float* sl = gslot + slot * SLOT + (r < nb ? r : 0) * 8 * H + dsrc;
+            const float ig = sl[0], fg = sl[H], gg = sl[2 * H], og = sl[3 * H], ct = sl[4 * H], cp = sl[5 * H];
+            const float th = tanh_f(ct);
+            cf[r].a = og * (1.f - th * th); cf[r].b = th * og * (1.f - og);
+            cf[r].ci = gg * ig * (1.f - ig); cf[r].cf = cp * fg * (1.f - fg); cf[r].cg = ig * (1.f - gg * gg);
+            cf[r].f = fg; cf[r].dhe = sl[6 * H]; cf[r].dce = sl[7 * H];
+        }
+    };
+    if (COOP) coefs(0);                                         // step T-1's inputs: staged and fenced above
     auto step = [&](int t, StepIn& slot, f32x4& cslot) {
         if (COOP) {
             const int it = T - 1 - t;                           // iteration counter: slot parity
-            const float* sl = gslot + (it & 1) * SLOT + dsrc;
-            const float ig = sl[0], fg = sl[H], gg = sl[2 * H], og = sl[3 * H], ct = sl[4 * H], cp = sl[5 * H];
-            const float dhe = sl[6 * H], dce = sl[7 * H];
+            float dgi[NR], dgf[NR], dgg[NR], dgo[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const float dh = dhd[r] + cf[r].dhe;
+                const float dct = dcd[r] + cf[r].dce + dh * cf[r].a;
+                dgo[r] = dh * cf[r].b;
+                dgi[r] = dct * cf[r].ci;
+                dgf[r] = dct * cf[r].cf;
+                dgg[r] = dct * cf[r].cg;
+                dcd[r] = dct * cf[r].f;
+                // rows >= nb and pad units of the gradient tile stay 0 (never written)
+                if (ulive && r < nb) {
+                    bf16* gw = gbuf + cur * 16 * ldg + r * ldg + ud;
+                    gw[0] = (bf16)dgi[r]; gw[HPAD] = (bf16)dgf[r]; gw[2 * HPAD] = (bf16)dgg[r]; gw[3 * HPAD] = (bf16)dgo[r];
+                }
+            }
             if (ld_on) *reinterpret_cast<f32x4*>(gslot + ((it + 1) & 1) * SLOT + lds_dst) = cslot;    // step t-1's chunk
             cfetch(cslot, t - 1 - PF);
-            const float dh = dhd + dhe;
-            const float th = tanh_f(ct);
-            const float dct = dcd + dce + dh * og * (1.f - th * th);
-            const float dgo = lvd * dh * th * og * (1.f - og);
-            const float dgi = lvd * dct * gg * ig * (1.f - ig);
-            const float dgf = lvd * dct * cp * fg * (1.f - fg);
-            const float dgg = lvd * dct * ig * (1.f - gg * gg);
-            dcd = dct * fg;
-            bf16* gw = gbuf + cur * 16 * ldg + ds * ldg + ud;
-            gw[0] = (bf16)dgi; gw[HPAD] = (bf16)dgf; gw[2 * HPAD] = (bf16)dgg; gw[3 * HPAD] = (bf16)dgo;
             lds_barrier();
-            if (lived) {
-                float* gp = dG + ((size_t)t * B + bd) * 4 * H + ud;
-                gp[0] = dgi; gp[H] = dgf; gp[2 * H] = dgg; gp[3 * H] = dgo;
-            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (ulive && r < nb) {
+                    float* gp = dG + ((size_t)t * B + bd0 + r) * 4 * H + ud;
+                    gp[0] = dgi[r]; gp[H] = dgf[r]; gp[2 * H] = dgg[r]; gp[3 * H] = dgo[r];
+                }
         } else {
             const StepIn in = slot;
             fetch(slot, t - PF);
@@ -379,14 +415,15 @@ __global__ __launch_bounds__(NT) void lstm_scan_bwd_kernel(const float* __restri
 #pragma unroll
             for (int ks = 0; ks < KG; ++ks) {
                 const bf16x8 af = WREG ? a[WREG ? k0 + ks : 0] : *reinterpret_cast<const bf16x8*>(wrow + (k0 + ks) * 32);
-                acc[ks & 3] = mfma16(af, bfr[ks], acc[ks & 3]);
+                acc[ks & 3] = COOP ? mfma16(bfr[ks], af, acc[ks & 3]) : mfma16(af, bfr[ks], acc[ks & 3]);
             }
             if (!WREG) __builtin_amdgcn_sched_barrier(0);       // keep the next group's fragment loads below this point
         }
+        if (COOP) coefs((T - t) & 1);                           // step t-1's inputs (slot written before this step's barrier), under the MFMAs
         dh_rec = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-        if (COOP) {                                             // re-deal dh_rec to the dense lanes (same-wave LDS: ordered)
-            if (l15 < 4) *reinterpret_cast<f32x4*>(xw + l15 * 16 + 4 * lq) = dh_rec;
-            dhd = xw[ds * 16 + du];
+        if (COOP) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) dhd[r] = dh_rec[r];   // sequence r, this lane's unit (lanes lq == 0)
         }
         cur ^= 1;
     };
@@ -398,10 +435,12 @@ __global__ __launch_bounds__(NT) void lstm_scan_bwd_kernel(const float* __restri
 #pragma unroll
     for (int d = 0; d < PF; ++d) if (tb - d >= 0) step(tb - d, ring[COOP ? 0 : d], cring[COOP ? d : 0]);
     if (COOP) {
-        if (lived) {
-            if (dh0) dh0[(size_t)bd * H + ud] = dhd;
-            if (dc0) dc0[(size_t)bd * H + ud] = dcd;
-        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (ulive && r < nb) {
+                if (dh0) dh0[(size_t)(bd0 + r) * H + ud] = dhd[r];
+                if (dc0) dc0[(size_t)(bd0 + r) * H + ud] = dcd[r];
+            }
     } else if (live) {
         if (dh0) *reinterpret_cast<f32x4*>(dh0 + (size_t)b * H + j0) = dh_rec;
         if (dc0) *reinterpret_cast<f32x4*>(dc0 + (size_t)b * H + j0) = dc;

@@ -41,7 +41,7 @@ def _oracle_lstm(gx, W, h0, c0):
 @pytest.mark.parametrize("T,B,H,init", [(20, 3, 88, False), (7, 17, 48, False), (50, 4, 128, True), (12, 33, 40, True),
                                         (1, 1, 16, False), (9, 5, 256, True),
                                         # > 256 sequences: 2 per workgroup; > 512: 4+ per workgroup and the per-lane loader
-                                        (6, 300, 88, True), (5, 601, 48, True), (4, 1100, 128, False),
+                                        (6, 300, 88, True), (5, 257, 64, True), (4, 259, 128, False), (5, 601, 48, True), (4, 1100, 128, False),
                                         # hidden sizes above 128: four workgroups per sequence up to 32 sequences, one beyond
                                         (40, 32, 256, True), (7, 3, 200, True), (5, 1, 132, False), (6, 40, 256, True), (3, 300, 160, False),
                                         # T = 1000 (configs[4]): the MFN cell sizes and the reference-default decoder size
