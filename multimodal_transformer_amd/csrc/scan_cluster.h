@@ -66,7 +66,6 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_cl4_kernel(const float* __r
     constexpr int KS = CL_KP / 32, LDH = CL_KP + 8;
     __shared__ __attribute__((aligned(16))) bf16 hbuf[2 * LDH];            // the sequence's h, bf16, double buffered
     __shared__ __attribute__((aligned(16))) float gslot[2 * 4 * CL_UW];    // [slot][gate][own unit]
-    __shared__ __attribute__((aligned(16))) float xch[4 * 4 * 16];         // per wave [gate][16 units]
     int b, part;
     cl_decode(b, part);
     if (b >= B) return;                                                    // whole workgroup
@@ -107,7 +106,6 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_cl4_kernel(const float* __r
     __syncthreads();
 
     cl_u64* xseq = xb + (size_t)b * 2 * CL_NP * 32;
-    float* xw = xch + w * 64;
     int cur = 0;
     bool dead = false;
     auto step = [&](int t, f32x4& in) {
@@ -121,20 +119,18 @@ __global__ __launch_bounds__(256) void lstm_scan_fwd_cl4_kernel(const float* __r
         f32x4 acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bf16* hb = hbuf + cur * LDH + 8 * lq;                        // only MFMA column 0 (the sequence) is live
+        // h W^T (scan.h, cooperative form): A = the h row — only row 0, the sequence, is live —, B = this wave's rows of W_rec, so
+        // register 0 of lanes 0..15 holds the pre-activation of the lane's own unit: no re-deal through LDS
+        const bf16* hb = hbuf + cur * LDH + 8 * lq;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             bf16x8 bf;
             if (l15 == 0) bf = *reinterpret_cast<const bf16x8*>(hb + ks * 32);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = mfma16(a[q][ks], bf, acc[q]);
+            for (int q = 0; q < 4; ++q) acc[q] = mfma16(bf, a[q][ks], acc[q]);
         }
-        if (l15 == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(xw + q * 16 + 4 * lq) = acc[q];
-        }
-        const float ig = sigmoid_f(xw[du] + gin[0]), fg = sigmoid_f(xw[16 + du] + gin[1]);
-        const float gg = tanh_f(xw[32 + du] + gin[2]), og = sigmoid_f(xw[48 + du] + gin[3]);
+        const float ig = sigmoid_f(acc[0][0] + gin[0]), fg = sigmoid_f(acc[1][0] + gin[1]);
+        const float gg = tanh_f(acc[2][0] + gin[2]), og = sigmoid_f(acc[3][0] + gin[3]);
         cd = fg * cd + ig * gg;
         const float hn = lived ? og * tanh_f(cd) : 0.f;
         // publish this wave's 16 new h values as 8 granules, then collect the other three workgroups' 96
@@ -180,7 +176,6 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_cl4_kernel(const float* __r
     constexpr int KP4 = 4 * CL_KP, KS4 = KP4 / 32, LDG = KP4 + 8;
     __shared__ __attribute__((aligned(16))) bf16 gbuf[2 * LDG];            // the sequence's gate gradients, k = gate*256 + unit
     __shared__ __attribute__((aligned(16))) float gslot[2 * 8 * CL_UW];    // [slot][segment][own unit]
-    __shared__ __attribute__((aligned(16))) float xch[4 * 16];
     int b, part;
     cl_decode(b, part);
     if (b >= B) return;
@@ -230,7 +225,6 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_cl4_kernel(const float* __r
     __syncthreads();
 
     cl_u64* xseq = xb + (size_t)b * 2 * CL_NP * 128;
-    float* xw = xch + w * 16;
     int cur = 0;
     bool dead = false;
     float dhd = 0.f, dcd = 0.f;
@@ -285,10 +279,9 @@ __global__ __launch_bounds__(256) void lstm_scan_bwd_cl4_kernel(const float* __r
         for (int kb = 0; kb < KS4; ++kb) {
             bf16x8 bfr;
             if (l15 == 0) bfr = *reinterpret_cast<const bf16x8*>(gb + kb * 32);
-            acc[kb & 3] = mfma16(a[kb], bfr, acc[kb & 3]);
+            acc[kb & 3] = mfma16(bfr, a[kb], acc[kb & 3]);      // dG W: row 0 = the sequence, column = this lane's unit
         }
-        if (l15 == 0) *reinterpret_cast<f32x4*>(xw + 4 * lq) = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-        dhd = xw[du];
+        dhd = ((acc[0] + acc[1]) + (acc[2] + acc[3]))[0];      // (lanes 0..15; the others hold rows that are not the sequence)
         cur ^= 1;
     };
     int tb = T - 1;
