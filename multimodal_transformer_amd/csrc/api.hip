@@ -1431,8 +1431,15 @@ static int mfn_mem_scan_forward_impl(const float* apre, const float* chat, const
     // (the gamma mask is not regenerated by the backward — u_all keeps the dropped values — so nothing reads the block after this launch)
     if (devseed && (rc = launch_seed_advance(seed_state, W.seedword, 1000, 1, st))) return rc;
     ProfScope prof(S_MEM_FWD, st);
-    hipLaunchKernelGGL(mfn_mem_scan_fwd_kernel, dim3((B + scan_bt(B) - 1) / scan_bt(B)), dim3(512), 0, st, apre, chat, W.WmF, W.W2F, b2, mem_all, u_all, g_all, T, B, scan_bt(B),
-                       stream_drop(dropout_p, seed, 1000, devseed, 16, 1000), devseed ? W.seedword : nullptr);
+    const int BT = scan_bt(B);
+    const DropCfg dcfg = stream_drop(dropout_p, seed, 1000, devseed, 16, 1000);
+    const uint64_t* sw = devseed ? W.seedword : nullptr;
+    if (BT == 1)        // one / two sequences per workgroup: units on the lanes (scan.h)
+        hipLaunchKernelGGL(mfn_mem_scan_fwd_sw_kernel<1>, dim3(B), dim3(512), 0, st, apre, chat, W.WmF, W.W2F, b2, mem_all, u_all, g_all, T, B, dcfg, sw);
+    else if (BT == 2)
+        hipLaunchKernelGGL(mfn_mem_scan_fwd_sw_kernel<2>, dim3((B + 1) / 2), dim3(512), 0, st, apre, chat, W.WmF, W.W2F, b2, mem_all, u_all, g_all, T, B, dcfg, sw);
+    else
+        hipLaunchKernelGGL(mfn_mem_scan_fwd_kernel, dim3((B + BT - 1) / BT), dim3(512), 0, st, apre, chat, W.WmF, W.W2F, b2, mem_all, u_all, g_all, T, B, BT, dcfg, sw);
     LAUNCH_CHECK("mfn_mem_scan_fwd_kernel");
     return MMT_OK;
 }
@@ -1462,8 +1469,15 @@ extern "C" int mmt_mfn_mem_scan_backward(const float* dmem_all, const float* cha
     hipLaunchKernelGGL(mfn_prep_kernel, dim3(64), dim3(256), 0, st, Wm, W2, W.WmF, W.W2F, W.WmB, W.W2B);
     LAUNCH_CHECK("mfn_prep_kernel");
     ProfScope prof(S_MEM_BWD, st);
-    hipLaunchKernelGGL(mfn_mem_scan_bwd_kernel, dim3((B + scan_bt(B) - 1) / scan_bt(B)), dim3(512), 0, st, dmem_all, chat, mem_all, u_all, g_all, W.WmB, W.W2B,
-                       dchat, dapre, dz_all, T, B, scan_bt(B), make_drop(dropout_p, 0, 0).scale);
+    const int BT = scan_bt(B);
+    const float dscale = make_drop(dropout_p, 0, 0).scale;
+    if (BT == 1)
+        hipLaunchKernelGGL(mfn_mem_scan_bwd_sw_kernel<1>, dim3(B), dim3(512), 0, st, dmem_all, chat, mem_all, u_all, g_all, W.WmB, W.W2B, dchat, dapre, dz_all, T, B, dscale);
+    else if (BT == 2)
+        hipLaunchKernelGGL(mfn_mem_scan_bwd_sw_kernel<2>, dim3((B + 1) / 2), dim3(512), 0, st, dmem_all, chat, mem_all, u_all, g_all, W.WmB, W.W2B, dchat, dapre, dz_all, T, B, dscale);
+    else
+        hipLaunchKernelGGL(mfn_mem_scan_bwd_kernel, dim3((B + BT - 1) / BT), dim3(512), 0, st, dmem_all, chat, mem_all, u_all, g_all, W.WmB, W.W2B,
+                           dchat, dapre, dz_all, T, B, BT, dscale);
     LAUNCH_CHECK("mfn_mem_scan_bwd_kernel");
     return MMT_OK;
 }

@@ -14,6 +14,13 @@
 
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp2(-1.4426950408889634f * x)); }
 __device__ __forceinline__ float tanh_f(float x) { return 2.0f * sigmoid_f(2.0f * x) - 1.0f; }
+// store to a wave-uniform base plus a 32-bit BYTE offset per lane as ONE instruction (`global_store_dword voff, vdata, s[base]`).
+// hipcc forms the 64-bit address in vector registers instead (a v_lshl_add_u64 per store: 6 of a forward step's ~120 instructions, and
+// a wave of these scans issues roughly one instruction per 10 cycles).  The stored values are many instructions old (the stores sit
+// behind the step's barrier), so no hazard the assembler statement would hide from the compiler applies.
+__device__ __forceinline__ void st_uniform(float* base, unsigned byte_off, float v) {
+    asm volatile("global_store_dword %0, %1, %2" :: "v"(byte_off), "v"(v), "s"(base) : "memory");
+}
 
 // W_rec (4H,H) fp32 -> forward operand Wf bf16 [4][HP16][HPAD] (Wf[q][j][k] = W[q*H+j][k]) and
 // backward operand Wb bf16 [HP16][4*HPAD] (Wb[j][q*HPAD+j'] = W[q*H+j'][j]); zero padded.
@@ -80,6 +87,7 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
     const int ud = jt * 16 + l15, udc = ud < H ? ud : H - 1;
     const int bd0 = blockIdx.x * BT;
     const bool ulive = COOP && (lq == 0) && (ud < H);
+    const unsigned uo[4] = {4u * (unsigned)ud, 4u * (unsigned)(ud + H), 4u * (unsigned)(ud + 2 * H), 4u * (unsigned)(ud + 3 * H)};   // byte offsets
     float cd[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) cd[r] = 0.f;
@@ -191,11 +199,12 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < NR; ++r)
                 if (ulive && r < nb) {
-                    const size_t o = ((size_t)t * B + bd0 + r) * H + ud;
-                    h_all[o] = hn[r];
-                    c_all[o] = cd[r];
-                    float* ap = acts + ((size_t)t * B + bd0 + r) * 4 * H + ud;
-                    ap[0] = ig[r]; ap[H] = fg[r]; ap[2 * H] = gg[r]; ap[3 * H] = og[r];
+                    // uniform base (scalar registers) + 32-bit lane offset: one instruction per store, no 64-bit vector address arithmetic
+                    const size_t o = ((size_t)t * B + bd0 + r) * H;
+                    st_uniform(h_all + o, uo[0], hn[r]);
+                    st_uniform(c_all + o, uo[0], cd[r]);
+                    float* ap = acts + o * 4;
+                    st_uniform(ap, uo[0], ig[r]); st_uniform(ap, uo[1], fg[r]); st_uniform(ap, uo[2], gg[r]); st_uniform(ap, uo[3], og[r]);
                 }
         } else {
             f32x4 ig, fg, gg, og, hn;
@@ -321,6 +330,7 @@ __global__ __launch_bounds__(NT) void lstm_scan_bwd_kernel(const float* __restri
     constexpr int NR = COOP ? COOP : 1;
     const int ud = jt * 16 + l15, bd0 = blockIdx.x * BT;
     const bool ulive = COOP && (lq == 0) && (ud < H);
+    const unsigned uo[4] = {4u * (unsigned)ud, 4u * (unsigned)(ud + H), 4u * (unsigned)(ud + 2 * H), 4u * (unsigned)(ud + 3 * H)};   // byte offsets
     const int dsrc = ud < H ? ud : H - 1;                       // + r * 8H
     float dhd[NR], dcd[NR];                                     // dh_rec / dc of the lane's unit
 #pragma unroll
@@ -366,8 +376,8 @@ __global__ __launch_bounds__(NT) void lstm_scan_bwd_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < NR; ++r)
                 if (ulive && r < nb) {
-                    float* gp = dG + ((size_t)t * B + bd0 + r) * 4 * H + ud;
-                    gp[0] = dgi[r]; gp[H] = dgf[r]; gp[2 * H] = dgg[r]; gp[3 * H] = dgo[r];
+                    float* gp = dG + ((size_t)t * B + bd0 + r) * 4 * H;      // uniform base + 32-bit lane offsets
+                    st_uniform(gp, uo[0], dgi[r]); st_uniform(gp, uo[1], dgf[r]); st_uniform(gp, uo[2], dgg[r]); st_uniform(gp, uo[3], dgo[r]);
                 }
         } else {
             const StepIn in = slot;
@@ -642,6 +652,214 @@ __global__ __launch_bounds__(512) void mfn_mem_scan_bwd_kernel(
         for (int ks = 0; ks < 4; ++ks)
             rec = mfma16(am[ks], *reinterpret_cast<const bf16x8*>(pbuf + l15 * LDP + ks * 32 + 8 * lq), rec);
         dcarry = dmg + rec;
+    };
+    int tb = T - 1;
+    for (; tb - PF + 1 >= 0; tb -= PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) step(tb - d, ring[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < PF; ++d) if (tb - d >= 0) step(tb - d, ring[d]);
+}
+
+// ---- the memory recurrence for ONE or TWO sequences per workgroup (batches of up to 512 sequences: 256 workgroups are in flight)
+// Same mathematics and the same dropout counters as the kernels above, with the MFMA operands swapped as in the cooperative LSTM
+// scans: the products are (state row) x W^T, so sequence r is register r of lanes 0..15 and every such lane owns ONE unit
+// j = 16 w + l15 of the wave (memory unit and row of u alike).  With the units in the registers and the sequence on the lane
+// (the general form above) four lanes of a wave carried four units each: every sigmoid, hash, pack and address of a step was
+// issued four times over for four live lanes.  Loads and stores are scalar per lane: 16 lanes x 4 bytes are one 64-byte segment.
+template <int NR>
+__global__ __launch_bounds__(512) void mfn_mem_scan_fwd_sw_kernel(
+        const float* __restrict__ apre, const float* __restrict__ chat, const bf16* __restrict__ WmF,
+        const bf16* __restrict__ W2F, const float* __restrict__ b2,
+        float* __restrict__ mem_all, float* __restrict__ u_all, float* __restrict__ g_all, int T, int B, DropCfg drop_in,
+        const uint64_t* __restrict__ seedword) {
+    const DropCfg drop = drop_resolve(drop_in, seedword);
+    __shared__ __attribute__((aligned(16))) bf16 membuf[16 * (MFN_MD + 8)];
+    __shared__ __attribute__((aligned(16))) bf16 ubuf[16 * (MFN_U + 8)];
+    constexpr int LDM = MFN_MD + 8, LDU = MFN_U + 8;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    const int b0 = blockIdx.x * NR, j = w * 16 + l15;
+    const int nb = (B - b0) < NR ? (B - b0) : NR;
+    const bool own = lq == 0;
+    bf16x8 am[4], a1[2], a2[2];                              // B fragments: column = this lane's unit, 8 consecutive k per lane quarter
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) am[ks] = *reinterpret_cast<const bf16x8*>(WmF + (size_t)j * MFN_MD + ks * 32 + 8 * lq);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a1[ks] = *reinterpret_cast<const bf16x8*>(W2F + (size_t)j * MFN_HG + ks * 32 + 8 * lq);
+        a2[ks] = *reinterpret_cast<const bf16x8*>(W2F + (size_t)(MFN_MD + j) * MFN_HG + ks * 32 + 8 * lq);
+    }
+    const float bias1 = b2[j], bias2 = b2[MFN_MD + j];
+    for (int i = threadIdx.x; i < 16 * LDM; i += blockDim.x) membuf[i] = (bf16)0.f;
+    for (int i = threadIdx.x; i < 16 * LDU; i += blockDim.x) ubuf[i] = (bf16)0.f;
+    __syncthreads();
+    float mem[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) mem[r] = 0.f;
+    constexpr int PF = 4;
+    struct In { float a[NR], c[NR]; };
+    In ring[PF];
+    auto fetch = [&](In& q, int t) {
+        const size_t rw = (size_t)(t < T ? t : T - 1) * B + b0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const size_t rr = rw + (r < nb ? r : 0);
+            q.a[r] = apre[rr * MFN_U + j];
+            q.c[r] = chat[rr * MFN_MD + j];
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < PF; ++d) fetch(ring[d], d);
+    const unsigned jo = 4u * (unsigned)j;
+    auto step = [&](int t, In& slot) {
+        const size_t row0 = (size_t)t * B + b0;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float ch[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { acc[r] = slot.a[r]; ch[r] = slot.c[r]; }
+        fetch(slot, t + PF);
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};                  // two accumulation chains
+#pragma unroll
+        for (int ks = 0; ks < 4; ks += 2) {
+            acc = mfma16(*reinterpret_cast<const bf16x8*>(membuf + l15 * LDM + ks * 32 + 8 * lq), am[ks], acc);
+            acc2 = mfma16(*reinterpret_cast<const bf16x8*>(membuf + l15 * LDM + (ks + 1) * 32 + 8 * lq), am[ks + 1], acc2);
+        }
+        float u[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            u[r] = fmaxf(acc[r] + acc2[r], 0.f);
+            if (drop.thr16) {      // gamma{1,2}_dropout on relu(fc1) (reference :222-223); u_all keeps the dropped values.  Same pair words as above
+                const uint32_t wd = drop_pair(drop, (uint64_t)(row0 + r) * MFN_U + (j & ~1));
+                u[r] = (j & 1) ? drop_hi(drop, wd, u[r]) : drop_lo(drop, wd, u[r]);
+            }
+            if (own && r < nb) ubuf[r * LDU + j] = (bf16)u[r];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < NR; ++r) if (own && r < nb) st_uniform(u_all + (row0 + r) * MFN_U, jo, u[r]);
+        f32x4 z1 = {bias1, bias1, bias1, bias1}, z2 = {bias2, bias2, bias2, bias2};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            z1 = mfma16(*reinterpret_cast<const bf16x8*>(ubuf + l15 * LDU + ks * 32 + 8 * lq), a1[ks], z1);
+            z2 = mfma16(*reinterpret_cast<const bf16x8*>(ubuf + l15 * LDU + MFN_HG + ks * 32 + 8 * lq), a2[ks], z2);
+        }
+        float g1[NR], g2[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            g1[r] = sigmoid_f(z1[r]); g2[r] = sigmoid_f(z2[r]);
+            mem[r] = g1[r] * mem[r] + g2[r] * ch[r];
+            if (own && r < nb) membuf[r * LDM + j] = (bf16)mem[r];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (own && r < nb) {
+                st_uniform(mem_all + (row0 + r) * MFN_MD, jo, mem[r]);
+                float* gp = g_all + (row0 + r) * 2 * MFN_MD;
+                st_uniform(gp, jo, g1[r]); st_uniform(gp + MFN_MD, jo, g2[r]);
+            }
+    };
+    int t0 = 0;
+    for (; t0 + PF <= T; t0 += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) step(t0 + d, ring[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < PF; ++d) if (t0 + d < T) step(t0 + d, ring[d]);
+}
+
+template <int NR>
+__global__ __launch_bounds__(512) void mfn_mem_scan_bwd_sw_kernel(
+        const float* __restrict__ dmem_ext, const float* __restrict__ chat, const float* __restrict__ mem_all,
+        const float* __restrict__ u_all, const float* __restrict__ g_all, const bf16* __restrict__ WmB, const bf16* __restrict__ W2B,
+        float* __restrict__ dchat, float* __restrict__ dapre, float* __restrict__ dz_all, int T, int B, float drop_scale) {
+    __shared__ __attribute__((aligned(16))) bf16 zbuf[16 * (2 * MFN_MD + 8)];
+    __shared__ __attribute__((aligned(16))) bf16 pbuf[16 * (MFN_U + 8)];
+    constexpr int LDZ = 2 * MFN_MD + 8, LDP = MFN_U + 8;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l15 = lane & 15, lq = lane >> 4;
+    const int b0 = blockIdx.x * NR, j = w * 16 + l15;
+    const int nb = (B - b0) < NR ? (B - b0) : NR;
+    const bool own = lq == 0;
+    const int gsel = (w * 16) / MFN_HG;                         // which gate MLP this wave's u rows belong to
+    bf16x8 a2[4], am[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        a2[ks] = *reinterpret_cast<const bf16x8*>(W2B + (size_t)j * MFN_MD + ks * 32 + 8 * lq);
+        am[ks] = *reinterpret_cast<const bf16x8*>(WmB + (size_t)j * MFN_U + ks * 32 + 8 * lq);
+    }
+    for (int i = threadIdx.x; i < 16 * LDZ; i += blockDim.x) zbuf[i] = (bf16)0.f;
+    for (int i = threadIdx.x; i < 16 * LDP; i += blockDim.x) pbuf[i] = (bf16)0.f;
+    __syncthreads();
+    float dcarry[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) dcarry[r] = 0.f;
+    constexpr int PF = 3;
+    struct In { float dme[NR], g1[NR], g2[NR], ch[NR], mp[NR], uu[NR]; };
+    In ring[PF];
+    auto fetch = [&](In& q, int t) {
+        const int tc = t > 0 ? t : 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const size_t rw = (size_t)tc * B + b0 + (r < nb ? r : 0);
+            q.dme[r] = dmem_ext ? dmem_ext[rw * MFN_MD + j] : 0.f;
+            q.g1[r] = g_all[rw * 2 * MFN_MD + j];
+            q.g2[r] = g_all[rw * 2 * MFN_MD + MFN_MD + j];
+            q.ch[r] = chat[rw * MFN_MD + j];
+            q.mp[r] = mem_all[(rw - (tc > 0 ? (size_t)B : 0)) * MFN_MD + j];
+            if (t <= 0) q.mp[r] = 0.f;                          // mem_{-1} = 0
+            q.uu[r] = u_all[rw * MFN_U + j];
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < PF; ++d) fetch(ring[d], T - 1 - d);
+    const unsigned jo = 4u * (unsigned)j;
+    auto step = [&](int t, In& slot) {
+        const size_t row0 = (size_t)t * B + b0;
+        const In in = slot;
+        fetch(slot, t - PF);
+        float dz1[NR], dz2[NR], dmg[NR], dch[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float dm = dcarry[r] + in.dme[r];
+            dz1[r] = dm * in.mp[r] * in.g1[r] * (1.f - in.g1[r]);
+            dz2[r] = dm * in.ch[r] * in.g2[r] * (1.f - in.g2[r]);
+            dch[r] = dm * in.g2[r];
+            dmg[r] = dm * in.g1[r];
+            if (own && r < nb) { zbuf[r * LDZ + j] = (bf16)dz1[r]; zbuf[r * LDZ + MFN_MD + j] = (bf16)dz2[r]; }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (own && r < nb) {
+                st_uniform(dchat + (row0 + r) * MFN_MD, jo, dch[r]);
+                float* zp = dz_all + (row0 + r) * 2 * MFN_MD;
+                st_uniform(zp, jo, dz1[r]); st_uniform(zp + MFN_MD, jo, dz2[r]);
+            }
+        // du of unit j = (W2_g^T dz_g)[j] ;  dpre = du * relu'(u)
+        f32x4 dua = {0.f, 0.f, 0.f, 0.f}, dub = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ks += 2) {
+            dua = mfma16(*reinterpret_cast<const bf16x8*>(zbuf + l15 * LDZ + gsel * MFN_MD + ks * 32 + 8 * lq), a2[ks], dua);
+            dub = mfma16(*reinterpret_cast<const bf16x8*>(zbuf + l15 * LDZ + gsel * MFN_MD + (ks + 1) * 32 + 8 * lq), a2[ks + 1], dub);
+        }
+        float du[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            du[r] = (in.uu[r] > 0.f) ? (dua[r] + dub[r]) * drop_scale : 0.f;      // u_all > 0 <=> relu passed AND kept
+            if (own && r < nb) pbuf[r * LDP + j] = (bf16)du[r];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < NR; ++r) if (own && r < nb) st_uniform(dapre + (row0 + r) * MFN_U, jo, du[r]);
+        f32x4 ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ks += 2) {
+            ra = mfma16(*reinterpret_cast<const bf16x8*>(pbuf + l15 * LDP + ks * 32 + 8 * lq), am[ks], ra);
+            rb = mfma16(*reinterpret_cast<const bf16x8*>(pbuf + l15 * LDP + (ks + 1) * 32 + 8 * lq), am[ks + 1], rb);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) dcarry[r] = dmg[r] + (ra[r] + rb[r]);
     };
     int tb = T - 1;
     for (; tb - PF + 1 >= 0; tb -= PF) {

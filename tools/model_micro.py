@@ -55,5 +55,5 @@ prof = _lib.profile_collect()
 _lib.profile(False)
 tot = sum(v[0] for v in prof.values()) / 3
 print("sum of profiled kernels %.3f ms/step" % tot)
-for name, (ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][0])[:14]:
+for name, (ms, cnt) in sorted(prof.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("MMT_TOP", "14"))]:
     print("  %-48s %8.3f ms/step  %4d launches/step  %8.1f us/launch" % (name, ms / 3, cnt // 3, 1e3 * ms / cnt))
