@@ -605,7 +605,26 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         }
         }
         __syncthreads();
-        if (p.colpart) {
+        if (p.colpart && !WIDE && MMT_ROWS == 32 && MMT_RTHREADS == 512 && NP == 128) {
+            // column sums of the 32-row tile on all 512 threads: wave w owns columns 16 w .. + 15, the lane's quarter rq the rows
+            // 4 rq + i and 16 + 4 rq + i (i < 4): with 132-float rows the two quarters of a 32-lane half sit 16 banks apart, so every
+            // read is conflict-free; the four quarters meet through two lane exchanges, in a fixed order
+            const int c = 16 * (tid >> 6) + (tid & 15), rq = (tid >> 4) & 3;
+            float sb = 0.f, sa = 0.f;
+#pragma unroll
+            for (int hh2 = 0; hh2 < 2; ++hh2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 16 * hh2 + 4 * rq + i;
+                    sb += Fs[r * ldf + c]; sa += Gs[r * (NP + 4) + c];
+                }
+            sb += __shfl_xor(sb, 16); sa += __shfl_xor(sa, 16);
+            sb += __shfl_xor(sb, 32); sa += __shfl_xor(sa, 32);
+            if (rq == 0) {
+                float* dst = p.colpart + (size_t)blockIdx.x * 2 * NP;
+                dst[c] = sb; dst[NP + c] = sa;
+            }
+        } else if (p.colpart) {
             for (int c = tid; c < NP; c += MMT_RTHREADS) {
                 float sb = 0.f, sa = 0.f;
                 if (!WIDE) {
