@@ -16,6 +16,7 @@
 #include "attn_bwd_diag.h"
 #include "misc_kernels.h"
 #include "scan.h"
+#include "scan_units.h"
 #include "scan256.h"
 #include "scan_cluster.h"
 #include "convpool.h"
@@ -1210,8 +1211,10 @@ extern "C" int mmt_lstm_scan_forward(const float* gx, const float* W_rec, const 
     const int BT = scan_bt(B);
     const dim3 grid((B + BT - 1) / BT), block(64 * (W.HP16 / 16));
     ProfScope prof(S_LSTM_FWD, st);
-#define MMT_LSTM_FWD(KS, NT, WREG, PF, COOP) hipLaunchKernelGGL((lstm_scan_fwd_kernel<KS, NT, WREG, PF, COOP>), grid, block, 0, st, \
+#define MMT_LSTM_FWD(KS, NT, WREG, PF) hipLaunchKernelGGL((lstm_scan_fwd_kernel<KS, NT, WREG, PF>), grid, block, 0, st, \
         gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16, BT)
+#define MMT_LSTM_FWD_U(KS, NT, WREG, PF, NR) hipLaunchKernelGGL((lstm_scan_fwd_u_kernel<KS, NT, WREG, PF, NR>), grid, block, 0, st, \
+        gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16)
     static const bool no_cluster = getenv("MMT_NO_CLUSTER_SCAN") != nullptr;
     const int cl_grid = 32 * ((B + 7) / 8);
     const int cl_fit = cl4_fits(&lstm_scan_fwd_cl4_kernel<3>, 0);
@@ -1227,22 +1230,23 @@ extern "C" int mmt_lstm_scan_forward(const float* gx, const float* W_rec, const 
     } else if (W.HPAD == 256 && BT == 1) {   // half-resident weights, one sequence per workgroup (scan256.h)
         hipLaunchKernelGGL((lstm_scan_fwd256_kernel<4, 1>), dim3(B), dim3(64 * ((W.HP16 + 31) / 32)), 0, st,
                            gx, W.Wf, h0, c0, h_all, c_all, acts, T, B, H, W.HP16);
-    } else if (BT <= 2) {       // cooperative step-input loader (see scan.h)
+    } else if (BT <= 2) {       // one / two sequences per workgroup: units on the lanes (scan_units.h)
         if (BT == 1) {
-            if (W.HPAD == 64) MMT_LSTM_FWD(2, 256, true, 4, 1);
-            else if (W.HPAD == 128) MMT_LSTM_FWD(4, 512, true, 4, 1);
-            else MMT_LSTM_FWD(8, 1024, false, 1, 1);
+            if (W.HPAD == 64) MMT_LSTM_FWD_U(2, 256, true, 6, 1);
+            else if (W.HPAD == 128) MMT_LSTM_FWD_U(4, 512, true, 6, 1);
+            else MMT_LSTM_FWD_U(8, 1024, false, 2, 1);
         } else {
-            if (W.HPAD == 64) MMT_LSTM_FWD(2, 256, true, 4, 2);
-            else if (W.HPAD == 128) MMT_LSTM_FWD(4, 512, true, 4, 2);
-            else MMT_LSTM_FWD(8, 1024, false, 1, 2);
+            if (W.HPAD == 64) MMT_LSTM_FWD_U(2, 256, true, 6, 2);
+            else if (W.HPAD == 128) MMT_LSTM_FWD_U(4, 512, true, 6, 2);
+            else MMT_LSTM_FWD_U(8, 1024, false, 1, 2);
         }
     } else {
-        if (W.HPAD == 64) MMT_LSTM_FWD(2, 256, true, 4, 0);
-        else if (W.HPAD == 128) MMT_LSTM_FWD(4, 512, true, 2, 0);
-        else MMT_LSTM_FWD(8, 1024, false, 1, 0);
+        if (W.HPAD == 64) MMT_LSTM_FWD(2, 256, true, 4);
+        else if (W.HPAD == 128) MMT_LSTM_FWD(4, 512, true, 2);
+        else MMT_LSTM_FWD(8, 1024, false, 1);
     }
 #undef MMT_LSTM_FWD
+#undef MMT_LSTM_FWD_U
     LAUNCH_CHECK("lstm_scan_fwd_kernel");
     return MMT_OK;
 }
@@ -1261,17 +1265,19 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
     const int BT = scan_bt(B);
     const dim3 grid((B + BT - 1) / BT), block(64 * (W.HP16 / 16));
     const bool coop = BT <= 2;
-    const size_t lds = (size_t)2 * 16 * (4 * W.HPAD + 8) * 2 + (coop ? ((size_t)2 * 2 * 8 * W.HPAD + 64 * (W.HP16 / 16)) * sizeof(float) : 0);
+    const size_t lds = (size_t)2 * 16 * (4 * W.HPAD + 8) * 2;
     static bool attr = false;
     if (!attr) {
-        if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false, 1, 0>))) return rc;
-        if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false, 2, 1>))) return rc;
-        if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false, 2, 2>))) return rc;
+        if ((rc = set_lds_attr(&lstm_scan_bwd_kernel<32, 1024, false, 1>))) return rc;
+        if ((rc = set_lds_attr(&lstm_scan_bwd_u_kernel<32, 1024, false, 2, 1>))) return rc;
+        if ((rc = set_lds_attr(&lstm_scan_bwd_u_kernel<32, 1024, false, 2, 2>))) return rc;
         attr = true;
     }
     ProfScope prof(S_LSTM_BWD, st);
-#define MMT_LSTM_BWD(KS4, NT, WREG, PF, COOP) hipLaunchKernelGGL((lstm_scan_bwd_kernel<KS4, NT, WREG, PF, COOP>), grid, block, lds, st, \
+#define MMT_LSTM_BWD(KS4, NT, WREG, PF) hipLaunchKernelGGL((lstm_scan_bwd_kernel<KS4, NT, WREG, PF>), grid, block, lds, st, \
         dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16, BT)
+#define MMT_LSTM_BWD_U(KS4, NT, WREG, PF, NR) hipLaunchKernelGGL((lstm_scan_bwd_u_kernel<KS4, NT, WREG, PF, NR>), grid, block, lds, st, \
+        dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16)
     static const bool no_cluster = getenv("MMT_NO_CLUSTER_SCAN") != nullptr;
     const int cl_fit = cl4_fits(&lstm_scan_bwd_cl4_kernel<2>, 1);
     const bool cluster = W.HPAD == 256 && B <= 32 && !no_cluster && cl_fit;
@@ -1291,20 +1297,21 @@ extern "C" int mmt_lstm_scan_backward(const float* dh_all, const float* dc_all, 
                            dh_all, dc_all, W.Wb, c0, c_all, acts, dgx, dh0, dc0, T, B, H, W.HP16);
     } else if (coop) {
         if (BT == 1) {
-            if (W.HPAD == 64) MMT_LSTM_BWD(8, 256, true, 4, 1);
-            else if (W.HPAD == 128) MMT_LSTM_BWD(16, 512, true, 4, 1);
-            else MMT_LSTM_BWD(32, 1024, false, 2, 1);
+            if (W.HPAD == 64) MMT_LSTM_BWD_U(8, 256, true, 6, 1);
+            else if (W.HPAD == 128) MMT_LSTM_BWD_U(16, 512, true, 6, 1);
+            else MMT_LSTM_BWD_U(32, 1024, false, 2, 1);
         } else {
-            if (W.HPAD == 64) MMT_LSTM_BWD(8, 256, true, 4, 2);
-            else if (W.HPAD == 128) MMT_LSTM_BWD(16, 512, true, 4, 2);
-            else MMT_LSTM_BWD(32, 1024, false, 2, 2);
+            if (W.HPAD == 64) MMT_LSTM_BWD_U(8, 256, true, 4, 2);
+            else if (W.HPAD == 128) MMT_LSTM_BWD_U(16, 512, true, 4, 2);
+            else MMT_LSTM_BWD_U(32, 1024, false, 2, 2);
         }
     } else {
-        if (W.HPAD == 64) MMT_LSTM_BWD(8, 256, true, 2, 0);
-        else if (W.HPAD == 128) MMT_LSTM_BWD(16, 512, true, 2, 0);
-        else MMT_LSTM_BWD(32, 1024, false, 1, 0);
+        if (W.HPAD == 64) MMT_LSTM_BWD(8, 256, true, 2);
+        else if (W.HPAD == 128) MMT_LSTM_BWD(16, 512, true, 2);
+        else MMT_LSTM_BWD(32, 1024, false, 1);
     }
 #undef MMT_LSTM_BWD
+#undef MMT_LSTM_BWD_U
     LAUNCH_CHECK("lstm_scan_bwd_kernel");
     return MMT_OK;
 }

@@ -41,22 +41,12 @@ __global__ void lstm_prep_kernel(const float* __restrict__ W, bf16* __restrict__
     }
 }
 
-// grid = ceil(B/16); block = 64 * (HP16/16) <= NT.  HPAD = 32*KS.  WREG: W_rec fragments stay in registers for the
+// grid = ceil(B/BT); block = 64 * (HP16/16) <= NT.  HPAD = 32*KS.  WREG: W_rec fragments stay in registers for the
 // whole scan (HPAD <= 128); otherwise (HPAD = 256: 512 KB of bf16 weights exceed one CU's register file) they are
 // re-streamed from L2 every step.  The time loop is straight-line code: lanes outside the batch / hidden range
-// compute on clamped addresses and simply do not store.
-// COOP (BT <= 2, i.e. batches of up to 512 sequences): the step inputs are fetched by the whole workgroup, one 16-byte
-// chunk per thread, PF steps ahead through a register ring and then a two-slot LDS ring.  With one or two live MFMA
-// columns a per-lane prefetch would park 16-32 VGPRs per step in flight in every lane for four useful lanes per wave,
-// which limits the depth to ~2 steps — less than the L2/MALL latency of the loads (measured: 1.6 of 2.1 us per step).
-// COOP = the workgroup's sequence count (1 or 2; 0: the general form).  The cooperative form also swaps the MFMA operands: the
-// product is h W^T (A = the h rows, B = the wave's W_rec rows), so the accumulator holds sequence 4*(lane>>4) + register and hidden
-// unit lane & 15 — the one or two live sequences are registers 0 / 1 of lanes 0..15, every live lane owns ONE hidden unit, and the
-// gate math runs on those registers directly.  (The other way round — units in the registers, the sequence on the lane — four
-// lanes of a wave hold 16 pre-activations each: either ten transcendentals per unit issue for four useful lanes, or the
-// accumulators go through an LDS patch to be re-dealt one unit per lane, which was a write, a wait and four reads on every step's
-// critical path.)
-template <int KS, int NT, bool WREG, int PF, int COOP>
+// compute on clamped addresses and simply do not store.  This is the form for 4..16 sequences per workgroup (batches above 512);
+// one or two sequences per workgroup run the kernels of scan_units.h.
+template <int KS, int NT, bool WREG, int PF>
 __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restrict__ gx, const bf16* __restrict__ Wf,
                                      const float* __restrict__ h0, const float* __restrict__ c0,
                                      float* __restrict__ h_all, float* __restrict__ c_all, float* __restrict__ acts,
@@ -81,25 +71,8 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
     }
     for (int i = threadIdx.x; i < 2 * 16 * ldh; i += blockDim.x) hbuf[i] = (bf16)0.f;
     __syncthreads();
-    // COOP: lane (lq == 0, l15) owns hidden unit ud of the workgroup's NR sequences (registers 0 .. NR-1 of its accumulators)
-    constexpr int NR = COOP ? COOP : 1;
-    const int nb = (B - (int)blockIdx.x * BT) < BT ? (B - (int)blockIdx.x * BT) : BT;
-    const int ud = jt * 16 + l15, udc = ud < H ? ud : H - 1;
-    const int bd0 = blockIdx.x * BT;
-    const bool ulive = COOP && (lq == 0) && (ud < H);
-    const unsigned uo[4] = {4u * (unsigned)ud, 4u * (unsigned)(ud + H), 4u * (unsigned)(ud + 2 * H), 4u * (unsigned)(ud + 3 * H)};   // byte offsets
-    float cd[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) cd[r] = 0.f;
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
-    if (COOP) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-            if (ulive && r < nb) {
-                if (c0) cd[r] = c0[(size_t)(bd0 + r) * H + ud];
-                if (h0) hbuf[r * ldh + ud] = (bf16)h0[(size_t)(bd0 + r) * H + ud];
-            }
-    } else if (live) {
+    if (live) {
         if (c0) c = *reinterpret_cast<const f32x4*>(c0 + (size_t)b * H + j0);
         if (h0) {
             const f32x4 hv = *reinterpret_cast<const f32x4*>(h0 + (size_t)b * H + j0);
@@ -111,60 +84,28 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
 
     const size_t gstep = (size_t)B * 4 * H;
     // input projections of the next PF steps are always in flight (register ring, statically indexed by unrolling)
-    constexpr int RW = COOP ? 1 : 4;
-    constexpr int SLOT = 2 * 4 * KP;                            // floats per LDS ring slot: [2 sequences][4H]
-    __shared__ __attribute__((aligned(16))) float gslot[COOP ? 2 * SLOT : 4];
-    f32x4 ring[PF][RW];
-    // per-lane form: this lane's 4 gate rows; cooperative form: chunk threadIdx.x of the workgroup's nb*4H floats
-    const bool ld_on = COOP ? ((int)threadIdx.x < nb * H) : true;
-    const int cb = ld_on ? (int)threadIdx.x / H : 0, co = ld_on ? 4 * ((int)threadIdx.x % H) : 0;
-    const float* gxl = COOP ? gx + ((size_t)(blockIdx.x * BT + cb) * 4 * H + co) : gx + (size_t)bc * 4 * H + jc;   // + t*gstep (+ q*H)
-    const int lds_dst = cb * 4 * H + co;
-    const int lds_src = udc;                                    // + r*4H + q*H: this lane's unit, gate q of sequence r
-    auto fetch = [&](f32x4 (&r)[RW], int t) {
+    f32x4 ring[PF][4];
+    const float* gxl = gx + (size_t)bc * 4 * H + jc;            // + t*gstep + q*H
+    auto fetch = [&](f32x4 (&r)[4], int t) {
         const int tl = t < T ? t : T - 1;                       // clamped: the tail re-reads the last step (unused)
 #pragma unroll
-        for (int q = 0; q < RW; ++q) r[q] = *reinterpret_cast<const f32x4*>(gxl + tl * gstep + (size_t)q * H);
+        for (int q = 0; q < 4; ++q) r[q] = *reinterpret_cast<const f32x4*>(gxl + tl * gstep + (size_t)q * H);
     };
-    if (COOP) {
-        f32x4 first[RW];
-        fetch(first, 0);
-        if (ld_on) *reinterpret_cast<f32x4*>(gslot + lds_dst) = first[0];
 #pragma unroll
-        for (int d = 0; d < PF; ++d) fetch(ring[d], d + 1);
-        __syncthreads();
-    } else {
-#pragma unroll
-        for (int d = 0; d < PF; ++d) fetch(ring[d], d);
-    }
+    for (int d = 0; d < PF; ++d) fetch(ring[d], d);
     int cur = 0;
-    auto step = [&](int t, f32x4 (&in)[RW]) {
+    auto step = [&](int t, f32x4 (&in)[4]) {
         f32x4 acc[4];
-        float gin[NR][4];
-        if (COOP) {
-            const float* sl = gslot + (t & 1) * SLOT + lds_src;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int r = 0; r < NR; ++r) gin[r][q] = sl[(r < nb ? r : 0) * 4 * H + q * H];
-            }
-            // hand step t+1's chunk to the other slot (its readers finished before the previous barrier), refill the ring
-            if (ld_on) *reinterpret_cast<f32x4*>(gslot + ((t + 1) & 1) * SLOT + lds_dst) = in[0];
-            fetch(in, t + 1 + PF);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = in[q < RW ? q : 0];
-            fetch(in, t + PF);
-        }
+        for (int q = 0; q < 4; ++q) acc[q] = in[q];
+        fetch(in, t + PF);
         const bf16* hb = hbuf + cur * 16 * ldh + l15 * ldh + 8 * lq;
         if (WREG) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 bf = *reinterpret_cast<const bf16x8*>(hb + ks * 32);
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc[q] = COOP ? mfma16(bf, a[WREG ? q : 0][WREG ? ks : 0], acc[q]) : mfma16(a[WREG ? q : 0][WREG ? ks : 0], bf, acc[q]);
+                for (int q = 0; q < 4; ++q) acc[q] = mfma16(a[WREG ? q : 0][WREG ? ks : 0], bf, acc[q]);
             }
         } else {
             // streamed weights: two k-blocks of fragments in flight; the scheduling fences keep hipcc from hoisting
@@ -180,53 +121,29 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
                 }
                 const bf16x8 bf = *reinterpret_cast<const bf16x8*>(hb + ks * 32);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = COOP ? mfma16(bf, wa[ks & 1][q], acc[q]) : mfma16(wa[ks & 1][q], bf, acc[q]);
+                for (int q = 0; q < 4; ++q) acc[q] = mfma16(wa[ks & 1][q], bf, acc[q]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (COOP) {
-            float ig[NR], fg[NR], gg[NR], og[NR], hn[NR];
+        f32x4 ig, fg, gg, og, hn;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                ig[r] = sigmoid_f(acc[0][r] + gin[r][0]); fg[r] = sigmoid_f(acc[1][r] + gin[r][1]);
-                gg[r] = tanh_f(acc[2][r] + gin[r][2]); og[r] = sigmoid_f(acc[3][r] + gin[r][3]);
-                cd[r] = fg[r] * cd[r] + ig[r] * gg[r];
-                hn[r] = og[r] * tanh_f(cd[r]);
-                // rows >= nb and units >= H of the h tile stay 0 (never written); lanes lq != 0 hold products of those zero rows
-                if (ulive && r < nb) hbuf[(cur ^ 1) * 16 * ldh + r * ldh + ud] = (bf16)hn[r];
-            }
-            lds_barrier();                                      // h_t visible to every wave; global traffic stays in flight
+        for (int r = 0; r < 4; ++r) {
+            ig[r] = sigmoid_f(acc[0][r]); fg[r] = sigmoid_f(acc[1][r]); gg[r] = tanh_f(acc[2][r]); og[r] = sigmoid_f(acc[3][r]);
+            c[r] = fg[r] * c[r] + ig[r] * gg[r];
+            hn[r] = live ? og[r] * tanh_f(c[r]) : 0.f;      // pad lanes keep h = 0 in LDS
+        }
+        bf16x4 hb4;
 #pragma unroll
-            for (int r = 0; r < NR; ++r)
-                if (ulive && r < nb) {
-                    // uniform base (scalar registers) + 32-bit lane offset: one instruction per store, no 64-bit vector address arithmetic
-                    const size_t o = ((size_t)t * B + bd0 + r) * H;
-                    st_uniform(h_all + o, uo[0], hn[r]);
-                    st_uniform(c_all + o, uo[0], cd[r]);
-                    float* ap = acts + o * 4;
-                    st_uniform(ap, uo[0], ig[r]); st_uniform(ap, uo[1], fg[r]); st_uniform(ap, uo[2], gg[r]); st_uniform(ap, uo[3], og[r]);
-                }
-        } else {
-            f32x4 ig, fg, gg, og, hn;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ig[r] = sigmoid_f(acc[0][r]); fg[r] = sigmoid_f(acc[1][r]); gg[r] = tanh_f(acc[2][r]); og[r] = sigmoid_f(acc[3][r]);
-                c[r] = fg[r] * c[r] + ig[r] * gg[r];
-                hn[r] = live ? og[r] * tanh_f(c[r]) : 0.f;      // pad lanes keep h = 0 in LDS
-            }
-            bf16x4 hb4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hb4[r] = (bf16)hn[r];
-            *reinterpret_cast<bf16x4*>(hbuf + (cur ^ 1) * 16 * ldh + l15 * ldh + jt * 16 + 4 * lq) = hb4;
-            lds_barrier();                                      // h_t visible to every wave; global traffic stays in flight
-            if (live) {
-                const size_t o = ((size_t)t * B + b) * H + j0;
-                *reinterpret_cast<f32x4*>(h_all + o) = hn;
-                *reinterpret_cast<f32x4*>(c_all + o) = c;
-                float* ap = acts + ((size_t)t * B + b) * 4 * H + j0;
-                *reinterpret_cast<f32x4*>(ap) = ig; *reinterpret_cast<f32x4*>(ap + H) = fg;
-                *reinterpret_cast<f32x4*>(ap + 2 * H) = gg; *reinterpret_cast<f32x4*>(ap + 3 * H) = og;
-            }
+        for (int r = 0; r < 4; ++r) hb4[r] = (bf16)hn[r];
+        *reinterpret_cast<bf16x4*>(hbuf + (cur ^ 1) * 16 * ldh + l15 * ldh + jt * 16 + 4 * lq) = hb4;
+        lds_barrier();                                      // h_t visible to every wave; global traffic stays in flight
+        if (live) {
+            const size_t o = ((size_t)t * B + b) * H + j0;
+            *reinterpret_cast<f32x4*>(h_all + o) = hn;
+            *reinterpret_cast<f32x4*>(c_all + o) = c;
+            float* ap = acts + ((size_t)t * B + b) * 4 * H + j0;
+            *reinterpret_cast<f32x4*>(ap) = ig; *reinterpret_cast<f32x4*>(ap + H) = fg;
+            *reinterpret_cast<f32x4*>(ap + 2 * H) = gg; *reinterpret_cast<f32x4*>(ap + 3 * H) = og;
         }
         cur ^= 1;
     };
@@ -241,7 +158,7 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_kernel(const float* __restri
 
 // Backward through time.  dG[t] (gate pre-activation gradients, fp32 (T,B,4H)) is also what the batched
 // input-projection / weight gradients consume afterwards.  KS4 = 4*HPAD/32.
-template <int KS4, int NT, bool WREG, int PF, int COOP>
+template <int KS4, int NT, bool WREG, int PF>
 __global__ __launch_bounds__(NT) void lstm_scan_bwd_kernel(const float* __restrict__ dh_ext, const float* __restrict__ dc_ext,
                                      const bf16* __restrict__ Wb, const float* __restrict__ c0,
                                      const float* __restrict__ c_all, const float* __restrict__ acts,
@@ -270,14 +187,11 @@ __global__ __launch_bounds__(NT) void lstm_scan_bwd_kernel(const float* __restri
     struct StepIn { f32x4 ig, fg, gg, og, ct, cp, dhe, dce; };
     const size_t ostep = (size_t)B * H;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    constexpr int SLOT = 2 * 8 * HPAD;                          // floats per LDS ring slot: [2 sequences][8H]
-    float* gslot = reinterpret_cast<float*>(smem + (size_t)2 * 16 * ldg * sizeof(bf16));   // COOP only: [2][SLOT]
-    // ---- per-lane form
-    StepIn ring[COOP ? 1 : PF];
+    StepIn ring[PF];
     const float* actl = acts + (size_t)bc * 4 * H + jc;
     const float* cl = c_all + (size_t)bc * H + jc;
     f32x4 c0v = zero4;
-    if (!COOP && c0) c0v = *reinterpret_cast<const f32x4*>(c0 + (size_t)bc * H + jc);
+    if (c0) c0v = *reinterpret_cast<const f32x4*>(c0 + (size_t)bc * H + jc);
     auto fetch = [&](StepIn& r, int t) {
         const int tc = t > 0 ? t : 0;                           // clamped, branch-free
         const float* ap = actl + (size_t)tc * ostep * 4;
@@ -289,123 +203,35 @@ __global__ __launch_bounds__(NT) void lstm_scan_bwd_kernel(const float* __restri
         r.dhe = dh_ext ? *reinterpret_cast<const f32x4*>(dh_ext + (size_t)bc * H + jc + (size_t)tc * ostep) : zero4;
         r.dce = dc_ext ? *reinterpret_cast<const f32x4*>(dc_ext + (size_t)bc * H + jc + (size_t)tc * ostep) : zero4;
     };
-    // ---- cooperative form: thread i owns chunk i of the workgroup's nb*8H floats per step:
-    //      [sequence][ i f g o (acts, 4H) | c_t | c_{t-1} | dh_ext | dc_ext ]
-    const int nb = (B - (int)blockIdx.x * BT) < BT ? (B - (int)blockIdx.x * BT) : BT;
-    const bool ld_on = COOP && ((int)threadIdx.x < nb * 2 * H);
-    const int cb = ld_on ? (int)threadIdx.x / (2 * H) : 0, cof = ld_on ? 4 * ((int)threadIdx.x % (2 * H)) : 0;
-    const int seg = cof / H, so = cof - seg * H;                // H % 4 == 0: a chunk never straddles two segments
-    const size_t cbg = (size_t)(blockIdx.x * BT + cb);
-    const float* cbase = seg < 4 ? acts + cbg * 4 * H + cof
-                       : seg < 6 ? c_all + cbg * H + so
-                       : seg == 6 ? (dh_ext ? dh_ext + cbg * H + so : c_all) : (dc_ext ? dc_ext + cbg * H + so : c_all);
-    const size_t cstride = seg < 4 ? ostep * 4 : ostep;
-    const int cshift = seg == 5 ? 1 : 0;                        // c_{t-1}
-    const bool czero = (seg == 6 && !dh_ext) || (seg == 7 && !dc_ext);      // absent external gradient: zeros
-    f32x4 cfirst = zero4;                                       // c_{-1} = c0
-    if (COOP && ld_on && seg == 5 && c0) cfirst = *reinterpret_cast<const f32x4*>(c0 + cbg * H + so);
-    f32x4 cring[COOP ? PF : 1];
-    auto cfetch = [&](f32x4& r, int t) {
-        const int tt = (t > 0 ? t : 0) - cshift;
-        f32x4 v = *reinterpret_cast<const f32x4*>(cbase + (size_t)(tt > 0 ? tt : 0) * cstride);
-        if (tt < 0) v = cfirst;
-        r = czero ? zero4 : v;
-    };
-    const int lds_dst = cb * 8 * H + cof;
-    const int lds_src = (l15 < nb ? l15 : 0) * 8 * H + jc;
-    if (COOP) {
-        f32x4 first;
-        cfetch(first, T - 1);
-        if (ld_on) *reinterpret_cast<f32x4*>(gslot + lds_dst) = first;
 #pragma unroll
-        for (int d = 0; d < PF; ++d) cfetch(cring[d], T - 2 - d);
-        __syncthreads();
-    } else {
-#pragma unroll
-        for (int d = 0; d < PF; ++d) fetch(ring[d], T - 1 - d);
-    }
+    for (int d = 0; d < PF; ++d) fetch(ring[d], T - 1 - d);
     int cur = 0;
-    // cooperative form (see the forward kernel): the product is dG W (A = the gate-gradient rows, B = the wave's rows of W^T), so lane
-    // (lq == 0, l15) owns hidden unit ud of the workgroup's NR sequences (registers 0 .. NR-1 of the accumulator)
-    constexpr int NR = COOP ? COOP : 1;
-    const int ud = jt * 16 + l15, bd0 = blockIdx.x * BT;
-    const bool ulive = COOP && (lq == 0) && (ud < H);
-    const unsigned uo[4] = {4u * (unsigned)ud, 4u * (unsigned)(ud + H), 4u * (unsigned)(ud + 2 * H), 4u * (unsigned)(ud + 3 * H)};   // byte offsets
-    const int dsrc = ud < H ? ud : H - 1;                       // + r * 8H
-    float dhd[NR], dcd[NR];                                     // dh_rec / dc of the lane's unit
+    auto step = [&](int t, StepIn& slot) {
+        const StepIn in = slot;
+        fetch(slot, t - PF);
+        f32x4 dgi, dgf, dgg, dgo;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) { dhd[r] = 0.f; dcd[r] = 0.f; }
-    // Everything of a step that does not depend on the recurrence (the saved activations' derivative factors, one tanh) is computed
-    // a step AHEAD, while the MFMAs of the step before run: what stays on the dh -> dgates -> dh chain is six multiply-adds.
-    struct Coef { float a, b, ci, cf, cg, f, dhe, dce; };      // dct = dc + dce + dh a;  dgo = dh b;  dgi/dgf/dgg = dct ci/cf/cg;  dc' = dct f
-    Coef cf[NR];
-    auto coefs = [&](int slot) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const float* sl = gslot + slot * SLOT + (r < nb ? r : 0) * 8 * H + dsrc;
-            const float ig = sl[0], fg = sl[H], gg = sl[2 * H], og = sl[3 * H], ct = sl[4 * H], cp = sl[5 * H];
-            const float th = tanh_f(ct);
-            cf[r].a = og * (1.f - th * th); cf[r].b = th * og * (1.f - og);
-            cf[r].ci = gg * ig * (1.f - ig); cf[r].cf = cp * fg * (1.f - fg); cf[r].cg = ig * (1.f - gg * gg);
-            cf[r].f = fg; cf[r].dhe = sl[6 * H]; cf[r].dce = sl[7 * H];
+        for (int r = 0; r < 4; ++r) {
+            const float dh = dh_rec[r] + in.dhe[r];
+            const float th = tanh_f(in.ct[r]);
+            const float dct = dc[r] + in.dce[r] + dh * in.og[r] * (1.f - th * th);
+            dgo[r] = lv * dh * th * in.og[r] * (1.f - in.og[r]);
+            dgi[r] = lv * dct * in.gg[r] * in.ig[r] * (1.f - in.ig[r]);
+            dgf[r] = lv * dct * in.cp[r] * in.fg[r] * (1.f - in.fg[r]);
+            dgg[r] = lv * dct * in.ig[r] * (1.f - in.gg[r] * in.gg[r]);
+            dc[r] = dct * in.fg[r];
         }
-    };
-    if (COOP) coefs(0);                                         // step T-1's inputs: staged and fenced above
-    auto step = [&](int t, StepIn& slot, f32x4& cslot) {
-        if (COOP) {
-            const int it = T - 1 - t;                           // iteration counter: slot parity
-            float dgi[NR], dgf[NR], dgg[NR], dgo[NR];
+        bf16* gw = gbuf + cur * 16 * ldg + l15 * ldg + jt * 16 + 4 * lq;
+        bf16x4 p0, p1, p2, p3;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const float dh = dhd[r] + cf[r].dhe;
-                const float dct = dcd[r] + cf[r].dce + dh * cf[r].a;
-                dgo[r] = dh * cf[r].b;
-                dgi[r] = dct * cf[r].ci;
-                dgf[r] = dct * cf[r].cf;
-                dgg[r] = dct * cf[r].cg;
-                dcd[r] = dct * cf[r].f;
-                // rows >= nb and pad units of the gradient tile stay 0 (never written)
-                if (ulive && r < nb) {
-                    bf16* gw = gbuf + cur * 16 * ldg + r * ldg + ud;
-                    gw[0] = (bf16)dgi[r]; gw[HPAD] = (bf16)dgf[r]; gw[2 * HPAD] = (bf16)dgg[r]; gw[3 * HPAD] = (bf16)dgo[r];
-                }
-            }
-            if (ld_on) *reinterpret_cast<f32x4*>(gslot + ((it + 1) & 1) * SLOT + lds_dst) = cslot;    // step t-1's chunk
-            cfetch(cslot, t - 1 - PF);
-            lds_barrier();
-#pragma unroll
-            for (int r = 0; r < NR; ++r)
-                if (ulive && r < nb) {
-                    float* gp = dG + ((size_t)t * B + bd0 + r) * 4 * H;      // uniform base + 32-bit lane offsets
-                    st_uniform(gp, uo[0], dgi[r]); st_uniform(gp, uo[1], dgf[r]); st_uniform(gp, uo[2], dgg[r]); st_uniform(gp, uo[3], dgo[r]);
-                }
-        } else {
-            const StepIn in = slot;
-            fetch(slot, t - PF);
-            f32x4 dgi, dgf, dgg, dgo;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float dh = dh_rec[r] + in.dhe[r];
-                const float th = tanh_f(in.ct[r]);
-                const float dct = dc[r] + in.dce[r] + dh * in.og[r] * (1.f - th * th);
-                dgo[r] = lv * dh * th * in.og[r] * (1.f - in.og[r]);
-                dgi[r] = lv * dct * in.gg[r] * in.ig[r] * (1.f - in.ig[r]);
-                dgf[r] = lv * dct * in.cp[r] * in.fg[r] * (1.f - in.fg[r]);
-                dgg[r] = lv * dct * in.ig[r] * (1.f - in.gg[r] * in.gg[r]);
-                dc[r] = dct * in.fg[r];
-            }
-            bf16* gw = gbuf + cur * 16 * ldg + l15 * ldg + jt * 16 + 4 * lq;
-            bf16x4 p0, p1, p2, p3;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { p0[r] = (bf16)dgi[r]; p1[r] = (bf16)dgf[r]; p2[r] = (bf16)dgg[r]; p3[r] = (bf16)dgo[r]; }
-            *reinterpret_cast<bf16x4*>(gw) = p0; *reinterpret_cast<bf16x4*>(gw + HPAD) = p1;
-            *reinterpret_cast<bf16x4*>(gw + 2 * HPAD) = p2; *reinterpret_cast<bf16x4*>(gw + 3 * HPAD) = p3;
-            lds_barrier();
-            if (live) {
-                float* gp = dG + ((size_t)t * B + b) * 4 * H + j0;
-                *reinterpret_cast<f32x4*>(gp) = dgi; *reinterpret_cast<f32x4*>(gp + H) = dgf;
-                *reinterpret_cast<f32x4*>(gp + 2 * H) = dgg; *reinterpret_cast<f32x4*>(gp + 3 * H) = dgo;
-            }
+        for (int r = 0; r < 4; ++r) { p0[r] = (bf16)dgi[r]; p1[r] = (bf16)dgf[r]; p2[r] = (bf16)dgg[r]; p3[r] = (bf16)dgo[r]; }
+        *reinterpret_cast<bf16x4*>(gw) = p0; *reinterpret_cast<bf16x4*>(gw + HPAD) = p1;
+        *reinterpret_cast<bf16x4*>(gw + 2 * HPAD) = p2; *reinterpret_cast<bf16x4*>(gw + 3 * HPAD) = p3;
+        lds_barrier();
+        if (live) {
+            float* gp = dG + ((size_t)t * B + b) * 4 * H + j0;
+            *reinterpret_cast<f32x4*>(gp) = dgi; *reinterpret_cast<f32x4*>(gp + H) = dgf;
+            *reinterpret_cast<f32x4*>(gp + 2 * H) = dgg; *reinterpret_cast<f32x4*>(gp + 3 * H) = dgo;
         }
         const bf16* gb = gbuf + cur * 16 * ldg + l15 * ldg + 8 * lq;
         // four independent accumulation chains (one per gate block of the contraction): a single chain of KS4
@@ -425,33 +251,21 @@ __global__ __launch_bounds__(NT) void lstm_scan_bwd_kernel(const float* __restri
 #pragma unroll
             for (int ks = 0; ks < KG; ++ks) {
                 const bf16x8 af = WREG ? a[WREG ? k0 + ks : 0] : *reinterpret_cast<const bf16x8*>(wrow + (k0 + ks) * 32);
-                acc[ks & 3] = COOP ? mfma16(bfr[ks], af, acc[ks & 3]) : mfma16(af, bfr[ks], acc[ks & 3]);
+                acc[ks & 3] = mfma16(af, bfr[ks], acc[ks & 3]);
             }
             if (!WREG) __builtin_amdgcn_sched_barrier(0);       // keep the next group's fragment loads below this point
         }
-        if (COOP) coefs((T - t) & 1);                           // step t-1's inputs (slot written before this step's barrier), under the MFMAs
         dh_rec = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-        if (COOP) {
-#pragma unroll
-            for (int r = 0; r < NR; ++r) dhd[r] = dh_rec[r];   // sequence r, this lane's unit (lanes lq == 0)
-        }
         cur ^= 1;
     };
     int tb = T - 1;
     for (; tb - PF + 1 >= 0; tb -= PF) {
 #pragma unroll
-        for (int d = 0; d < PF; ++d) step(tb - d, ring[COOP ? 0 : d], cring[COOP ? d : 0]);
+        for (int d = 0; d < PF; ++d) step(tb - d, ring[d]);
     }
 #pragma unroll
-    for (int d = 0; d < PF; ++d) if (tb - d >= 0) step(tb - d, ring[COOP ? 0 : d], cring[COOP ? d : 0]);
-    if (COOP) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-            if (ulive && r < nb) {
-                if (dh0) dh0[(size_t)(bd0 + r) * H + ud] = dhd[r];
-                if (dc0) dc0[(size_t)(bd0 + r) * H + ud] = dcd[r];
-            }
-    } else if (live) {
+    for (int d = 0; d < PF; ++d) if (tb - d >= 0) step(tb - d, ring[d]);
+    if (live) {
         if (dh0) *reinterpret_cast<f32x4*>(dh0 + (size_t)b * H + j0) = dh_rec;
         if (dc0) *reinterpret_cast<f32x4*>(dc0 + (size_t)b * H + j0) = dc;
     }
