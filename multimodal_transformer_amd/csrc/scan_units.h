@@ -65,19 +65,26 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_u_kernel(const float* __rest
     const float* gxl = gx + (size_t)bd0 * 4 * H + udc;
     struct In { float g[NR][4]; };
     In ring[PF];
-    auto fetch = [&](In& q, int t) {
-        const float* p = gxl + (size_t)(t < T ? t : T - 1) * gstep;     // clamped: the tail re-reads the last step (unused)
+    // (uniform offsets are carried from step to step — an add and a select — instead of being formed as 64-bit products of the step index)
+    size_t foff = 0;                                            // float offset of the next step to fetch; stops at the last step
+    int tf = 0;
+    const size_t r1 = (size_t)(nb > 1 ? 1 : 0) * 4 * H;
+    auto fetch = [&](In& q) {
+        const float* p = gxl + foff;
 #pragma unroll
         for (int r = 0; r < NR; ++r)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) q.g[r][g] = p[(size_t)(r < nb ? r : 0) * 4 * H + (size_t)g * H];
+            for (int g = 0; g < 4; ++g) q.g[r][g] = p[(r ? r1 : 0) + (size_t)g * H];
+        foff += (tf < T - 1) ? gstep : 0;                       // the tail re-reads the last step (unused)
+        ++tf;
     };
 #pragma unroll
-    for (int d = 0; d < PF; ++d) fetch(ring[d], d);
+    for (int d = 0; d < PF; ++d) fetch(ring[d]);
+    size_t soff = (size_t)bd0 * H;                              // float offset of (step t, sequence bd0) in h_all / c_all
     int cur = 0;
     auto step = [&](int t, In& slot) {
         const In in = slot;
-        fetch(slot, t + PF);
+        fetch(slot);
         f32x4 acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -121,12 +128,14 @@ __global__ __launch_bounds__(NT) void lstm_scan_fwd_u_kernel(const float* __rest
 #pragma unroll
         for (int r = 0; r < NR; ++r)
             if (ulive && r < nb) {
-                const size_t o = ((size_t)t * B + bd0 + r) * H;
+                const size_t o = soff + (size_t)r * H;
                 st_uniform(h_all + o, uo[0], hn[r]);
                 st_uniform(c_all + o, uo[0], cd[r]);
                 float* ap = acts + o * 4;
                 st_uniform(ap, uo[0], ig[r]); st_uniform(ap, uo[1], fg[r]); st_uniform(ap, uo[2], gg[r]); st_uniform(ap, uo[3], og[r]);
             }
+        soff += (size_t)B * H;
+        (void)t;
         cur ^= 1;
     };
     int t0 = 0;
@@ -171,19 +180,35 @@ __global__ __launch_bounds__(NT) void lstm_scan_bwd_u_kernel(const float* __rest
     struct In { float ig[NR], fg[NR], gg[NR], og[NR], ct[NR], cp[NR], dhe[NR], dce[NR]; };
     const size_t ostep = (size_t)B * H;
     In ring[PF];
-    auto fetch = [&](In& q, int t) {
-        const int tc = t > 0 ? t : 0;                           // clamped, branch-free
+    // (uniform offsets are carried from step to step — a subtract and a select — instead of being formed as 64-bit products of the
+    // step index: that was half of the scalar instructions of a step)
+    // Absent optional inputs (external gradients, c0) read a valid dummy and are scaled by 0: no branches in the time loop.
+    int tf = T - 1;                                             // the step the next fetch is for; < 0: re-reads step 0 (unused)
+    size_t foff = (size_t)(T - 1) * ostep;                      // tc * ostep, tc = max(tf, 0)
+    const float* const dhp = dh_ext ? dh_ext : c_all;
+    const float* const dcp = dc_ext ? dc_ext : c_all;
+    const float dhs = dh_ext ? 1.f : 0.f, dcs = dc_ext ? 1.f : 0.f;
+    size_t bo[NR];
+    float c0v[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        bo[r] = (size_t)(bd0 + (r < nb ? r : 0)) * H + udc;
+        c0v[r] = c0 ? c0[bo[r]] : 0.f;                          // c_{-1} = c0
+    }
+    auto fetch = [&](In& q) {
+        const size_t fprev = foff - (tf > 0 ? ostep : 0);       // (tc - 1) * ostep, clamped
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const size_t bo = (size_t)(bd0 + (r < nb ? r : 0)) * H + udc;
-            const float* ap = acts + ((size_t)tc * ostep + (size_t)(bd0 + (r < nb ? r : 0)) * H) * 4 + udc;
+            const float* ap = acts + foff * 4 + bo[r] * 4 - 3 * (size_t)udc;      // (foff + seq*H)*4 + udc
             q.ig[r] = ap[0]; q.fg[r] = ap[H]; q.gg[r] = ap[2 * H]; q.og[r] = ap[3 * H];
-            q.ct[r] = c_all[(size_t)tc * ostep + bo];
-            const float cprev = c_all[(size_t)(tc > 0 ? tc - 1 : 0) * ostep + bo];
-            q.cp[r] = (t > 0) ? cprev : (c0 ? c0[bo] : 0.f);    // c_{-1} = c0
-            q.dhe[r] = dh_ext ? dh_ext[(size_t)tc * ostep + bo] : 0.f;
-            q.dce[r] = dc_ext ? dc_ext[(size_t)tc * ostep + bo] : 0.f;
+            q.ct[r] = c_all[foff + bo[r]];
+            const float cprev = c_all[fprev + bo[r]];
+            q.cp[r] = (tf > 0) ? cprev : c0v[r];
+            q.dhe[r] = dhp[foff + bo[r]];
+            q.dce[r] = dcp[foff + bo[r]];
         }
+        foff = fprev;
+        --tf;
     };
     struct Coef { float a, b, ci, cf, cg, f, dhe, dce; };      // dct = dc + dce + dh a;  dgo = dh b;  dgi/dgf/dgg = dct ci/cf/cg;  dc' = dct f
     Coef cf[NR];
@@ -194,19 +219,20 @@ __global__ __launch_bounds__(NT) void lstm_scan_bwd_u_kernel(const float* __rest
             cf[r].a = q.og[r] * (1.f - th * th); cf[r].b = th * q.og[r] * (1.f - q.og[r]);
             cf[r].ci = q.gg[r] * q.ig[r] * (1.f - q.ig[r]); cf[r].cf = q.cp[r] * q.fg[r] * (1.f - q.fg[r]);
             cf[r].cg = q.ig[r] * (1.f - q.gg[r] * q.gg[r]);
-            cf[r].f = q.fg[r]; cf[r].dhe = q.dhe[r]; cf[r].dce = q.dce[r];
+            cf[r].f = q.fg[r]; cf[r].dhe = q.dhe[r] * dhs; cf[r].dce = q.dce[r] * dcs;
         }
     };
 #pragma unroll
-    for (int d = 0; d < PF; ++d) fetch(ring[d], T - 1 - d);
+    for (int d = 0; d < PF; ++d) fetch(ring[d]);
     coefs(ring[0]);
+    size_t goff = ((size_t)(T - 1) * B + bd0) * 4 * H;          // float offset of (step t, sequence bd0) in dG
     float dhd[NR], dcd[NR];                                     // dh_rec / dc of the lane's unit
 #pragma unroll
     for (int r = 0; r < NR; ++r) { dhd[r] = 0.f; dcd[r] = 0.f; }
     int cur = 0;
     // slot: the ring entry of step t (its factors are in cf already: free to refill); next: the entry of step t - 1
     auto step = [&](int t, In& slot, const In& next) {
-        fetch(slot, t - PF);
+        fetch(slot);
         float dgi[NR], dgf[NR], dgg[NR], dgo[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -227,7 +253,7 @@ __global__ __launch_bounds__(NT) void lstm_scan_bwd_u_kernel(const float* __rest
 #pragma unroll
         for (int r = 0; r < NR; ++r)
             if (ulive && r < nb) {
-                float* gp = dG + ((size_t)t * B + bd0 + r) * 4 * H;
+                float* gp = dG + goff + (size_t)r * 4 * H;
                 st_uniform(gp, uo[0], dgi[r]); st_uniform(gp, uo[1], dgf[r]); st_uniform(gp, uo[2], dgg[r]); st_uniform(gp, uo[3], dgo[r]);
             }
         const bf16* gb = gbuf + cur * 16 * ldg + l15 * ldg + 8 * lq;   // A fragments: row l15 = sequence l15 (only rows < NR are read)
@@ -252,6 +278,8 @@ __global__ __launch_bounds__(NT) void lstm_scan_bwd_u_kernel(const float* __rest
         const f32x4 dh_rec = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 #pragma unroll
         for (int r = 0; r < NR; ++r) dhd[r] = dh_rec[r];       // sequence r, this lane's unit (lanes lq == 0)
+        goff -= (size_t)B * 4 * H;
+        (void)t;
         cur ^= 1;
     };
     int tb = T - 1;
