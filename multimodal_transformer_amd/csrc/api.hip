@@ -254,11 +254,29 @@ static int launch_rowgemm(const RowGemmParams& p, hipStream_t st, int site = S_O
     return MMT_OK;
 }
 
+// layer 0's single-stage launches, fixed-shape instances (rowgemm.h): same LDS bytes as the generic kernel computes for these shapes
+template <typename K>
+static int launch_rowgemm_fixed(K kernel, const RowGemmParams& p, size_t lds, hipStream_t st, int site, const char* name) {
+    static const void* configured[4] = {};
+    const void* kp = reinterpret_cast<const void*>(kernel);
+    bool seen = false;
+    for (int i = 0; i < 4; ++i) seen = seen || configured[i] == kp;
+    if (!seen) {
+        HIP_TRY(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int i = 0; i < 4; ++i) if (!configured[i]) { configured[i] = kp; break; }
+    }
+    ProfScope prof(site, st);
+    hipLaunchKernelGGL(kernel, dim3((p.M + MMT_ROWS - 1) / MMT_ROWS), dim3(MMT_RTHREADS), lds, st, p);
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) return fail(MMT_EHIP, "launch of %s failed: %s", name, hipGetErrorString(e_));
+    return MMT_OK;
+}
+
 static int chain_extra_kp(const RowChain3&) { return 0; }
 static int chain_extra_kp(const RowChain4& ch) { return ch.d.KP; }
 
 template <typename K, typename CH>
-static int launch_rowchain(K kernel, CH& ch, bool lnbwd, int site, const char* name, hipStream_t st, int lnb_np = 0) {
+static int launch_rowchain(K kernel, CH& ch, bool lnbwd, int site, const char* name, hipStream_t st, int lnb_np = 0, int shape = 0) {
     // lnbwd: the chain holds LayerNorm-backward stages of output width lnb_np (default: stage b's)
     // LDS geometry shared by the stages
     const int akp = (ch.a.kchunk > 0 && ch.a.kchunk < ch.a.KP) ? ch.a.kchunk : ch.a.KP;     // K-chunked first stage: one chunk in LDS
@@ -273,13 +291,18 @@ static int launch_rowchain(K kernel, CH& ch, bool lnbwd, int site, const char* n
     const bool with_g = lnbwd && !(ch.a.no_gs || ch.b.no_gs || ch.c.no_gs);      // ... and a second fp32 tile unless the column sums recompute x-hat
     const size_t lds = rowchain_lds_bytes(ch, with_g);
     if (lds > 160 * 1024) return fail(MMT_EUNSUPPORTED, "fused row chain needs %zu B of LDS", lds);
-    static const void* configured[8] = {};       // every chain kernel of one argument type shares this instantiation
+    if (shape == 128) {          // the fixed-shape instance carves its LDS from constants (rowgemm.h): they must be this geometry
+        const bool ok = ch.ldf == MMT_FIX128_LDF && ch.lda2 == MMT_FIX128_LDA2 && (ch.lda_max == MMT_FIX128_LDA_FWD || ch.lda_max == MMT_FIX128_LDA_BND)
+                        && with_g == lnbwd && ch.ldx == (lnbwd ? 0 : 132);
+        if (!ok) return fail(MMT_EHIP, "internal: LDS geometry of %s (%d, %d, %d, %d) is not the fixed instance's", name, ch.lda_max, ch.ldf, ch.ldx, ch.lda2);
+    }
+    static const void* configured[16] = {};       // every chain kernel of one argument type shares this instantiation
     const void* kp = reinterpret_cast<const void*>(kernel);
     bool seen = false;
-    for (int i = 0; i < 8; ++i) seen = seen || configured[i] == kp;
+    for (int i = 0; i < 16; ++i) seen = seen || configured[i] == kp;
     if (!seen) {
         HIP_TRY(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        for (int i = 0; i < 8; ++i) if (!configured[i]) { configured[i] = kp; break; }
+        for (int i = 0; i < 16; ++i) if (!configured[i]) { configured[i] = kp; break; }
     }
     ProfScope prof(site, st);
     hipLaunchKernelGGL(kernel, dim3((ch.a.M + MMT_ROWS - 1) / MMT_ROWS), dim3(MMT_RTHREADS), lds, st, ch);
@@ -288,6 +311,13 @@ static int launch_rowchain(K kernel, CH& ch, bool lnbwd, int site, const char* n
     return MMT_OK;
 }
 
+// Fixed-shape instances of the chain kernels (rowgemm.h): 128 = d_model = d_ff = h d_k = 128 with 8 heads of 16 (configs[3]); 0 = generic
+static int chain_shape(int d, int f, int h, const LayerLayout& L) {
+    static const bool off = getenv("MMT_NO_FIXED_SHAPES") != nullptr;
+    if (off) return 0;
+    if (d == 128 && L.DP == 128 && f == 128 && L.FP == 128 && L.HDP == 128 && L.NQ == 384 && h == 8 && L.DKP == 16) return 128;
+    return 0;
+}
 static RowGemmParams rg_zero() { RowGemmParams p; memset(&p, 0, sizeof(p)); p.mask_scale = 1.0f; return p; }
 
 static DropCfg no_drop() { return make_drop(0.f, 0, 0); }
@@ -481,6 +511,7 @@ static int encoder_forward_impl(const float* x, const float* mask, const float* 
         LAUNCH_CHECK("encoder_prep_kernel");
     }
     const float* xin = x;
+    const int shape = chain_shape(d, f, h, L);
     static const bool fuse_next_qkv = getenv("MMT_NO_CHAIN4") == nullptr;
     for (int l = 0; l < D.N; ++l) {
         const LayerWs& w = W.lw[l];
@@ -504,7 +535,9 @@ static int encoder_forward_impl(const float* x, const float* mask, const float* 
         };
         if (l == 0) {
             RowGemmParams p = qkv_params(0, xin);
-            if ((rc = launch_rowgemm<EPI_FRAG, true>(p, st, S_LN1_QKV))) return rc;
+            if (shape == 128) rc = launch_rowgemm_fixed(encoder_ln1_qkv128_kernel, p, rowgemm_lds_bytes(EPI_FRAG, true, 128, 384), st, S_LN1_QKV, "encoder_ln1_qkv128_kernel");
+            else rc = launch_rowgemm<EPI_FRAG, true>(p, st, S_LN1_QKV);
+            if (rc) return rc;
         }
         // dropout streams of layer l: 4l+0 attention probabilities (:33), 4l+1 / 4l+3 sublayer outputs (:104), 4l+2 FFN hidden (:20)
         if ((rc = launch_attn_fwd(L.DKP, w.QR, w.KR, w.VR, w.ctx, w.lse, D, st, mkdrop(4 * l + 0), w.maskQ))) return rc;
@@ -533,15 +566,17 @@ static int encoder_forward_impl(const float* x, const float* mask, const float* 
                 RowChain4 c4; memset(&c4, 0, sizeof(c4));
                 c4.a = ch.a; c4.b = ch.b; c4.c = ch.c; c4.ldx = ch.ldx; c4.lda2 = ch.lda2;
                 c4.d = qkv_params(l + 1, nullptr);                 // A operand: the x2 tile in LDS
-                if ((rc = launch_rowchain(devseed ? encoder_post_attn_fwd4_kernel<true> : encoder_post_attn_fwd4_kernel<false>, c4, false, S_CHAIN4_FWD,
-                                          "encoder_post_attn_fwd4_kernel", st))) return rc;
+                auto k4 = shape == 128 ? (devseed ? encoder_post_attn_fwd4_kernel<true, 128> : encoder_post_attn_fwd4_kernel<false, 128>)
+                                       : (devseed ? encoder_post_attn_fwd4_kernel<true, 0> : encoder_post_attn_fwd4_kernel<false, 0>);
+                if ((rc = launch_rowchain(k4, c4, false, S_CHAIN4_FWD, "encoder_post_attn_fwd4_kernel", st, 0, shape))) return rc;
             } else {
                 if (l + 1 == D.N) {        // last layer: the stack's final LayerNorm runs on the output tile while it is in LDS
                     const float* Pf = params + (size_t)D.N * L.stride();
                     ch.ln.a = Pf; ch.ln.b = Pf + d; ch.ln.eps = eps; ch.ln.y = y; ch.ln.stats = W.statsf; ch.ln.d = d;
                 }
-                if ((rc = launch_rowchain(devseed ? encoder_post_attn_fwd_kernel<true> : encoder_post_attn_fwd_kernel<false>, ch, false, S_OUTPROJ,
-                                          "encoder_post_attn_fwd_kernel", st))) return rc;
+                auto k3 = shape == 128 ? (devseed ? encoder_post_attn_fwd_kernel<true, 128> : encoder_post_attn_fwd_kernel<false, 128>)
+                                       : (devseed ? encoder_post_attn_fwd_kernel<true, 0> : encoder_post_attn_fwd_kernel<false, 0>);
+                if ((rc = launch_rowchain(k3, ch, false, S_OUTPROJ, "encoder_post_attn_fwd_kernel", st, 0, shape))) return rc;
                 if (l + 1 < D.N) {
                     RowGemmParams p = qkv_params(l + 1, w.xout);
                     if ((rc = launch_rowgemm<EPI_FRAG, true>(p, st, S_LN1_QKV))) return rc;
@@ -675,15 +710,18 @@ static int encoder_backward_impl(const float* dy, const float* x, const float* m
     };
     // Layers l >= 1 close (bwd_qkv + LayerNorm-1 backward) inside the kernel that opens layer l-1 (encoder_bwd_boundary_kernel) unless
     // MMT_NO_BWD_BOUNDARY=1
+    const int shape = chain_shape(d, f, h, L);
     static const bool fuse_boundary = getenv("MMT_NO_BWD_BOUNDARY") == nullptr;
     const bool boundary = fuse_boundary;
     for (int l = D.N - 1; l >= 0; --l) {
         const LayerWs& w = W.lw[l];
         if (l == D.N - 1 || !boundary) {
             RowChain3 ch; build_chain(l, ch);
+            const int sh = ch.b.no_gs ? 0 : shape;
             auto k3 = ch.b.no_gs ? (devseed ? encoder_pre_attn_bwd_kernel<true, true> : encoder_pre_attn_bwd_kernel<true, false>)
-                                 : (devseed ? encoder_pre_attn_bwd_kernel<false, true> : encoder_pre_attn_bwd_kernel<false, false>);
-            rc = launch_rowchain(k3, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st);
+                    : sh == 128 ? (devseed ? encoder_pre_attn_bwd_kernel<false, true, 128> : encoder_pre_attn_bwd_kernel<false, false, 128>)
+                                : (devseed ? encoder_pre_attn_bwd_kernel<false, true> : encoder_pre_attn_bwd_kernel<false, false>);
+            rc = launch_rowchain(k3, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st, 0, sh);
             if (rc) return rc;
         }
         if ((rc = launch_attn_bwd(L.DKP, w.QR, w.KR, w.VR, W.dOR, w.lse, W.delta, mask,
@@ -697,13 +735,20 @@ static int encoder_backward_impl(const float* dy, const float* x, const float* m
             c4.a.seedword = seedword;
             c4.b = below.a; c4.c = below.b; c4.d = below.c; c4.ldx = 0; c4.lda2 = below.lda2;
             if (c4.a.no_gs != c4.c.no_gs) { c4.a.no_gs = c4.c.no_gs = 1; }        // (one WIDE flag per kernel: K-chunking alone implies it)
+            const int sh = (c4.a.no_gs || c4.a.kchunk) ? 0 : shape;
             auto k4 = c4.a.no_gs ? (devseed ? encoder_bwd_boundary_kernel<true, true> : encoder_bwd_boundary_kernel<true, false>)
-                                 : (devseed ? encoder_bwd_boundary_kernel<false, true> : encoder_bwd_boundary_kernel<false, false>);
-            rc = launch_rowchain(k4, c4, true, S_BWD_BOUNDARY, "encoder_bwd_boundary_kernel", st, L.DP);
+                    : sh == 128 ? (devseed ? encoder_bwd_boundary_kernel<false, true, 128> : encoder_bwd_boundary_kernel<false, false, 128>)
+                                : (devseed ? encoder_bwd_boundary_kernel<false, true> : encoder_bwd_boundary_kernel<false, false>);
+            rc = launch_rowchain(k4, c4, true, S_BWD_BOUNDARY, "encoder_bwd_boundary_kernel", st, L.DP, sh);
             if (rc) return rc;
         } else {
             RowGemmParams p = build_qkv(l, dxin);
-            if ((rc = launch_rowgemm<EPI_LNBWD, false>(p, st, S_BWD_QKV_LN1))) return rc;
+            if (shape == 128 && !p.no_gs && !p.kchunk) {
+                p.seedword = seedword;
+                rc = launch_rowgemm_fixed(devseed ? encoder_bwd_qkv_ln1_128_kernel<true> : encoder_bwd_qkv_ln1_128_kernel<false>, p,
+                                          rowgemm_lds_bytes(EPI_LNBWD, false, 384, 128), st, S_BWD_QKV_LN1, "encoder_bwd_qkv_ln1_128_kernel");
+            } else rc = launch_rowgemm<EPI_LNBWD, false>(p, st, S_BWD_QKV_LN1);
+            if (rc) return rc;
         }
         // weight-gradient jobs of this layer (run later, all layers in one launch)
         const size_t so = (size_t)l * W.slab_stride;

@@ -777,11 +777,21 @@ __device__ __forceinline__ RowGemmParams role_bwd_relu(RowGemmParams p) {       
 // Forward, after the attention core of a layer:   x1 = x + drop(ctx Wo^T + bo)        (out-proj + residual; x1 kept in LDS)
 //                                                 hid = drop(relu(LN2(x1) W1^T + b1))  (hid kept in LDS as the next A tile)
 //                                                 x2 = x1 + drop(hid W2^T + b2)        (residual read from LDS)
-template <bool DEVSEED>
+template <int K_, int N_> __device__ __forceinline__ RowGemmParams shape_pin(RowGemmParams p);
+template <int LDA_MAX, int LDF, bool WITH_G, int LDX, int LDA2> __device__ __forceinline__ RowSmem carve_fixed(char* smem);
+template <bool DEVSEED, int SHAPE = 0>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_post_attn_fwd_kernel(const RowChain3 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const RowSmem sm = rowchain_carve(smem, ch, false);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
+    if (SHAPE == 128) {                                         // (fixed-shape instances: see below)
+        const RowSmem sm = carve_fixed<136, 132, false, 132, 136>(smem);
+        rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X, DEVSEED>(shape_pin<128, 128>(role_plain(ch.a)), sm);
+        rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2, DEVSEED>(shape_pin<128, 128>(role_ffn1(ch.b)), sm);
+        rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X, DEVSEED>(shape_pin<128, 128>(role_plain(ch.c)), sm);
+        if (ch.ln.y) ln_tile_out(sm.Xs, sm.ldx, ch.ln, ch.c.M);
+        return;
+    }
+    const RowSmem sm = rowchain_carve(smem, ch, false);
     rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X, DEVSEED>(role_plain(ch.a), sm);
     rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2, DEVSEED>(role_ffn1(ch.b), sm);
     rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X, DEVSEED>(role_plain(ch.c), sm);
@@ -790,27 +800,92 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
 
 // The same chain followed by the NEXT layer's LayerNorm-1 + Q/K/V projection (its input x2 is already in LDS): every
 // layer but the last.  One launch and one round trip of the residual stream less per layer.
-template <bool DEVSEED>
+// ---- fixed-shape instances.  The chains above take every width, stride and the LDS geometry at run time; 70 % of their static
+// instruction stream was integer / scalar bookkeeping (address arithmetic, bounds compares, branches) around 12 % floating point.
+// For the widths of the BASELINE configs the host selects an instance in which the stages' shapes, leading dimensions and the LDS
+// carve are pinned like the roles (shape_pin, carve_fixed): the arithmetic folds into immediates (configs[3]: 2 879 -> 1 989
+// static instructions in the 4-stage forward chain, -11 % time).  SHAPE: 0 = generic; 128 = d_model = d_ff = h d_k = 128, 8 heads of 16.
+template <int K_, int N_> __device__ __forceinline__ RowGemmParams shape_pin(RowGemmParams p) {
+    p.K = K_; p.KP = K_; p.N = N_; p.NP = N_;
+    p.lda = K_; p.lda_out = K_;                                 // A row-major [M][K] (and its bf16 copy)
+    p.ldr = N_; p.ldo = N_; p.ldo16 = N_; p.n_store16 = N_; p.ldm = N_;      // outputs, residual, ReLU mask: [M][N]
+    p.ldx = N_; p.lddres = N_; p.d_real = N_; p.next_lda = N_ + 8; p.ldctx = N_;   // LayerNorm backward (N = d_model), next A tile, dO's ctx
+    return p;
+}
+template <int LDA_MAX, int LDF, bool WITH_G, int LDX, int LDA2>
+__device__ __forceinline__ RowSmem carve_fixed(char* smem) {
+    RowSmem sm;
+    sm.As = reinterpret_cast<bf16*>(smem);
+    sm.Fs = reinterpret_cast<float*>(smem + (size_t)MMT_ROWS * LDA_MAX * 2);
+    sm.ldf = LDF;
+    sm.Gs = sm.Fs + (size_t)MMT_ROWS * LDF;
+    sm.Xs = sm.Fs + (size_t)MMT_ROWS * LDF * (WITH_G ? 2 : 1);
+    sm.ldx = LDX;
+    sm.A2 = reinterpret_cast<bf16*>(sm.Xs + (size_t)MMT_ROWS * LDX);
+    sm.lda2 = LDA2;
+    return sm;
+}
+// the geometry launch_rowchain (api.hip) computes for SHAPE 128; it refuses the fixed instance when its own numbers differ
+#define MMT_FIX128_LDF 132
+#define MMT_FIX128_LDA2 136
+#define MMT_FIX128_LDA_FWD 136
+#define MMT_FIX128_LDA_BND 392
+__device__ __forceinline__ RowGemmParams qkv128(RowGemmParams p) { p = shape_pin<128, 384>(p); p.lda_out = 128; p.h = 8; p.DKP = 16; return p; }
+__device__ __forceinline__ RowGemmParams dO128(RowGemmParams p) { p = shape_pin<128, 128>(p); p.h = 8; p.DKP = 16; return p; }
+
+template <bool DEVSEED, int SHAPE = 0>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_post_attn_fwd4_kernel(const RowChain4 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const RowSmem sm = rowchain_carve(smem, ch, false);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
     warm_weights(ch.d.W, ch.d.NP, ch.d.KP);
+    if (SHAPE == 128) {
+        const RowSmem sm = carve_fixed<MMT_FIX128_LDA_FWD, MMT_FIX128_LDF, false, 132, MMT_FIX128_LDA2>(smem);
+        rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X, DEVSEED>(shape_pin<128, 128>(role_plain(ch.a)), sm);
+        rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2, DEVSEED>(shape_pin<128, 128>(role_ffn1(ch.b)), sm);
+        rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X, DEVSEED>(shape_pin<128, 128>(role_plain(ch.c)), sm);
+        rowgemm_stage<EPI_FRAG, true, ASRC_X, 0, false>(qkv128(role_qkv(ch.d)), sm);
+        return;
+    }
+    const RowSmem sm = rowchain_carve(smem, ch, false);
     rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X, DEVSEED>(role_plain(ch.a), sm);
     rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2, DEVSEED>(role_ffn1(ch.b), sm);
     rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X, DEVSEED>(role_plain(ch.c), sm);
     rowgemm_stage<EPI_FRAG, true, ASRC_X, 0, false>(role_qkv(ch.d), sm);
 }
 
+// layer 0's two single-stage launches as fixed-shape instances (SHAPE 128)
+__global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_ln1_qkv128_kernel(const RowGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const RowSmem sm = carve_fixed<MMT_FIX128_LDA_FWD, MMT_FIX128_LDF, false, 0, 0>(smem);
+    RowGemmParams q = qkv128(role_qkv(p));
+    q.lda = 128;
+    rowgemm_stage<EPI_FRAG, true, ASRC_GLOBAL, 0, false>(q, sm);
+}
+template <bool DEVSEED>
+__global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_bwd_qkv_ln1_128_kernel(const RowGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const RowSmem sm = carve_fixed<MMT_FIX128_LDA_BND, MMT_FIX128_LDF, true, 0, 0>(smem);
+    RowGemmParams q = shape_pin<384, 128>(role_lnbwd(p));
+    q.next_drop.thr16 = 0; q.kchunk = 0; q.no_gs = 0;
+    rowgemm_stage<EPI_LNBWD, false, ASRC_GLOBAL, 0, DEVSEED, false>(q, sm);
+}
+
 // Backward, from the layer-output gradient dx2 down to the attention core's operands:
 //     dh  = (drop'(dx2) W2) * relu'(hid) * drop'          (dh kept in LDS as the next A tile; dx2^T, dh^T emitted for dW)
 //     dx1 = dx2 + LN2bwd(dh W1)                            (drop'(dx1) kept in LDS as the next A tile)
 //     dO  = drop'(dx1) Wo  -> fragment layouts + delta     (dx1^T emitted for dW)
-template <bool WIDE, bool DEVSEED>
+template <bool WIDE, bool DEVSEED, int SHAPE = 0>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_pre_attn_bwd_kernel(const RowChain3 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP);
+    if (SHAPE == 128 && !WIDE) {
+        const RowSmem sm = carve_fixed<MMT_FIX128_LDA_FWD, MMT_FIX128_LDF, true, 0, MMT_FIX128_LDA2>(smem);
+        rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_A2, DEVSEED>(shape_pin<128, 128>(role_bwd_relu(ch.a)), sm);
+        rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(shape_pin<128, 128>(role_lnbwd(ch.b)), sm);
+        rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(dO128(role_dO(ch.c)), sm);
+        return;
+    }
+    const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
     rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_A2, DEVSEED>(role_bwd_relu(ch.a), sm);
     rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(role_lnbwd(ch.b), sm);      // dx1 -> global (fp32) and, as the next A tile, LDS (bf16)
     rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(role_dO(ch.c), sm);
@@ -823,11 +898,19 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
 // workgroup barriers, each draining the stores, in between) and, dropped and rounded to bf16, straight into the next A tile.  One
 // launch and one staging pass less per layer than `bwd_qkv+ln1` followed by the chain.  (WIDE: 83 KB of LDS at d_model = 256, one
 // workgroup per CU — at that width two workgroups sharing a CU take twice as long each anyway)
-template <bool WIDE, bool DEVSEED>
+template <bool WIDE, bool DEVSEED, int SHAPE = 0>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_bwd_boundary_kernel(const RowChain4 ch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
     warm_weights(ch.b.W, ch.b.NP, ch.b.KP); warm_weights(ch.c.W, ch.c.NP, ch.c.KP); warm_weights(ch.d.W, ch.d.NP, ch.d.KP);
+    if (SHAPE == 128 && !WIDE) {
+        const RowSmem sm = carve_fixed<MMT_FIX128_LDA_BND, MMT_FIX128_LDF, true, 0, MMT_FIX128_LDA2>(smem);
+        rowgemm_stage<EPI_LNBWD, false, ASRC_GLOBAL, KEEP_AS, DEVSEED, WIDE>(shape_pin<384, 128>(role_lnbwd(ch.a)), sm);
+        rowgemm_stage<EPI_PLAIN, false, ASRC_AS, KEEP_A2, DEVSEED>(shape_pin<128, 128>(role_bwd_relu(ch.b)), sm);
+        rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(shape_pin<128, 128>(role_lnbwd(ch.c)), sm);
+        rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(dO128(role_dO(ch.d)), sm);
+        return;
+    }
+    const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
     rowgemm_stage<EPI_LNBWD, false, ASRC_GLOBAL, KEEP_AS, DEVSEED, WIDE>(role_lnbwd(ch.a), sm);        // layer l:   dx -> global (fp32) + next A tile (bf16, dropped)
     rowgemm_stage<EPI_PLAIN, false, ASRC_AS, KEEP_A2, DEVSEED>(role_bwd_relu(ch.b), sm);                     // layer l-1: dh
     rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(role_lnbwd(ch.c), sm);                              //            dx1
