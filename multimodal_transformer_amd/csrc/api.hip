@@ -296,6 +296,12 @@ static int launch_rowchain(K kernel, CH& ch, bool lnbwd, int site, const char* n
                         && with_g == lnbwd && ch.ldx == (lnbwd ? 0 : 132);
         if (!ok) return fail(MMT_EHIP, "internal: LDS geometry of %s (%d, %d, %d, %d) is not the fixed instance's", name, ch.lda_max, ch.ldf, ch.ldx, ch.lda2);
     }
+    if (shape == 256) {
+        const bool ok = ch.lda2 == MMT_FIX256_LDA2 && !with_g &&
+                        (lnbwd ? (ch.ldf == MMT_FIX256_LDF_BWD && ch.ldx == 0 && (ch.lda_max == MMT_FIX256_LDA || ch.lda_max == MMT_FIX256_LDA_BND))
+                               : (ch.ldf == MMT_FIX256_LDF_FWD && ch.ldx == MMT_FIX256_LDX && ch.lda_max == MMT_FIX256_LDA));
+        if (!ok) return fail(MMT_EHIP, "internal: LDS geometry of %s (%d, %d, %d, %d) is not the fixed instance's", name, ch.lda_max, ch.ldf, ch.ldx, ch.lda2);
+    }
     static const void* configured[16] = {};       // every chain kernel of one argument type shares this instantiation
     const void* kp = reinterpret_cast<const void*>(kernel);
     bool seen = false;
@@ -316,6 +322,7 @@ static int chain_shape(int d, int f, int h, const LayerLayout& L) {
     static const bool off = getenv("MMT_NO_FIXED_SHAPES") != nullptr;
     if (off) return 0;
     if (d == 128 && L.DP == 128 && f == 128 && L.FP == 128 && L.HDP == 128 && L.NQ == 384 && h == 8 && L.DKP == 16) return 128;
+    if (d == 256 && L.DP == 256 && f == 128 && L.FP == 128 && L.HDP == 256 && L.NQ == 768 && h == 8 && L.DKP == 32) return 256;   // MFT stacks
     return 0;
 }
 static RowGemmParams rg_zero() { RowGemmParams p; memset(&p, 0, sizeof(p)); p.mask_scale = 1.0f; return p; }
@@ -567,6 +574,7 @@ static int encoder_forward_impl(const float* x, const float* mask, const float* 
                 c4.a = ch.a; c4.b = ch.b; c4.c = ch.c; c4.ldx = ch.ldx; c4.lda2 = ch.lda2;
                 c4.d = qkv_params(l + 1, nullptr);                 // A operand: the x2 tile in LDS
                 auto k4 = shape == 128 ? (devseed ? encoder_post_attn_fwd4_kernel<true, 128> : encoder_post_attn_fwd4_kernel<false, 128>)
+                        : shape == 256 ? (devseed ? encoder_post_attn_fwd4_kernel<true, 256> : encoder_post_attn_fwd4_kernel<false, 256>)
                                        : (devseed ? encoder_post_attn_fwd4_kernel<true, 0> : encoder_post_attn_fwd4_kernel<false, 0>);
                 if ((rc = launch_rowchain(k4, c4, false, S_CHAIN4_FWD, "encoder_post_attn_fwd4_kernel", st, 0, shape))) return rc;
             } else {
@@ -575,6 +583,7 @@ static int encoder_forward_impl(const float* x, const float* mask, const float* 
                     ch.ln.a = Pf; ch.ln.b = Pf + d; ch.ln.eps = eps; ch.ln.y = y; ch.ln.stats = W.statsf; ch.ln.d = d;
                 }
                 auto k3 = shape == 128 ? (devseed ? encoder_post_attn_fwd_kernel<true, 128> : encoder_post_attn_fwd_kernel<false, 128>)
+                        : shape == 256 ? (devseed ? encoder_post_attn_fwd_kernel<true, 256> : encoder_post_attn_fwd_kernel<false, 256>)
                                        : (devseed ? encoder_post_attn_fwd_kernel<true, 0> : encoder_post_attn_fwd_kernel<false, 0>);
                 if ((rc = launch_rowchain(k3, ch, false, S_OUTPROJ, "encoder_post_attn_fwd_kernel", st, 0, shape))) return rc;
                 if (l + 1 < D.N) {
@@ -717,8 +726,9 @@ static int encoder_backward_impl(const float* dy, const float* x, const float* m
         const LayerWs& w = W.lw[l];
         if (l == D.N - 1 || !boundary) {
             RowChain3 ch; build_chain(l, ch);
-            const int sh = ch.b.no_gs ? 0 : shape;
-            auto k3 = ch.b.no_gs ? (devseed ? encoder_pre_attn_bwd_kernel<true, true> : encoder_pre_attn_bwd_kernel<true, false>)
+            const int sh = ch.b.no_gs ? (shape == 256 ? 256 : 0) : (shape == 128 ? 128 : 0);
+            auto k3 = sh == 256 ? (devseed ? encoder_pre_attn_bwd_kernel<true, true, 256> : encoder_pre_attn_bwd_kernel<true, false, 256>)
+                    : ch.b.no_gs ? (devseed ? encoder_pre_attn_bwd_kernel<true, true> : encoder_pre_attn_bwd_kernel<true, false>)
                     : sh == 128 ? (devseed ? encoder_pre_attn_bwd_kernel<false, true, 128> : encoder_pre_attn_bwd_kernel<false, false, 128>)
                                 : (devseed ? encoder_pre_attn_bwd_kernel<false, true> : encoder_pre_attn_bwd_kernel<false, false>);
             rc = launch_rowchain(k3, ch, true, S_BWD_FFN2, "encoder_pre_attn_bwd_kernel", st, 0, sh);
@@ -735,8 +745,9 @@ static int encoder_backward_impl(const float* dy, const float* x, const float* m
             c4.a.seedword = seedword;
             c4.b = below.a; c4.c = below.b; c4.d = below.c; c4.ldx = 0; c4.lda2 = below.lda2;
             if (c4.a.no_gs != c4.c.no_gs) { c4.a.no_gs = c4.c.no_gs = 1; }        // (one WIDE flag per kernel: K-chunking alone implies it)
-            const int sh = (c4.a.no_gs || c4.a.kchunk) ? 0 : shape;
-            auto k4 = c4.a.no_gs ? (devseed ? encoder_bwd_boundary_kernel<true, true> : encoder_bwd_boundary_kernel<true, false>)
+            const int sh = (c4.a.no_gs || c4.a.kchunk) ? ((shape == 256 && c4.a.no_gs && c4.a.kchunk == 512) ? 256 : 0) : (shape == 128 ? 128 : 0);
+            auto k4 = sh == 256 ? (devseed ? encoder_bwd_boundary_kernel<true, true, 256> : encoder_bwd_boundary_kernel<true, false, 256>)
+                    : c4.a.no_gs ? (devseed ? encoder_bwd_boundary_kernel<true, true> : encoder_bwd_boundary_kernel<true, false>)
                     : sh == 128 ? (devseed ? encoder_bwd_boundary_kernel<false, true, 128> : encoder_bwd_boundary_kernel<false, false, 128>)
                                 : (devseed ? encoder_bwd_boundary_kernel<false, true> : encoder_bwd_boundary_kernel<false, false>);
             rc = launch_rowchain(k4, c4, true, S_BWD_BOUNDARY, "encoder_bwd_boundary_kernel", st, L.DP, sh);

@@ -791,6 +791,14 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
         if (ch.ln.y) ln_tile_out(sm.Xs, sm.ldx, ch.ln, ch.c.M);
         return;
     }
+    if (SHAPE == 256) {
+        const RowSmem sm = carve_fixed<264, 132, false, 260, 136>(smem);
+        rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X, DEVSEED>(shape_pin<256, 256>(role_plain(ch.a)), sm);
+        rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2, DEVSEED>(shape_pin<256, 128>(role_ffn1(ch.b)), sm);
+        rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X, DEVSEED>(shape_pin<128, 256>(role_plain(ch.c)), sm);
+        if (ch.ln.y) ln_tile_out(sm.Xs, sm.ldx, ch.ln, ch.c.M);
+        return;
+    }
     const RowSmem sm = rowchain_carve(smem, ch, false);
     rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X, DEVSEED>(role_plain(ch.a), sm);
     rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2, DEVSEED>(role_ffn1(ch.b), sm);
@@ -832,6 +840,17 @@ __device__ __forceinline__ RowSmem carve_fixed(char* smem) {
 #define MMT_FIX128_LDA_BND 392
 __device__ __forceinline__ RowGemmParams qkv128(RowGemmParams p) { p = shape_pin<128, 384>(p); p.lda_out = 128; p.h = 8; p.DKP = 16; return p; }
 __device__ __forceinline__ RowGemmParams dO128(RowGemmParams p) { p = shape_pin<128, 128>(p); p.h = 8; p.DKP = 16; return p; }
+// SHAPE 256 = the MFT's per-modality stacks (configs[2], configs[4]): d_model = h d_k = 256 (8 heads of 32), d_ff = 128; the backward
+// chains are the WIDE instances (K-chunked dQKV tile, x-hat recomputed)
+#define MMT_FIX256_LDA 264
+#define MMT_FIX256_LDA_BND 520
+#define MMT_FIX256_LDF_FWD 132
+#define MMT_FIX256_LDF_BWD 260
+#define MMT_FIX256_LDX 260
+#define MMT_FIX256_LDA2 136
+__device__ __forceinline__ RowGemmParams qkv256(RowGemmParams p) { p = shape_pin<256, 768>(p); p.lda_out = 256; p.h = 8; p.DKP = 32; return p; }
+__device__ __forceinline__ RowGemmParams dO256(RowGemmParams p) { p = shape_pin<256, 256>(p); p.h = 8; p.DKP = 32; return p; }
+__device__ __forceinline__ RowGemmParams lnbwd256(RowGemmParams p) { p.no_gs = 1; return p; }
 
 template <bool DEVSEED, int SHAPE = 0>
 __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 512) ? 4 : 2) void encoder_post_attn_fwd4_kernel(const RowChain4 ch) {
@@ -844,6 +863,14 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
         rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2, DEVSEED>(shape_pin<128, 128>(role_ffn1(ch.b)), sm);
         rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X, DEVSEED>(shape_pin<128, 128>(role_plain(ch.c)), sm);
         rowgemm_stage<EPI_FRAG, true, ASRC_X, 0, false>(qkv128(role_qkv(ch.d)), sm);
+        return;
+    }
+    if (SHAPE == 256) {
+        const RowSmem sm = carve_fixed<MMT_FIX256_LDA, MMT_FIX256_LDF_FWD, false, MMT_FIX256_LDX, MMT_FIX256_LDA2>(smem);
+        rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_X, DEVSEED>(shape_pin<256, 256>(role_plain(ch.a)), sm);
+        rowgemm_stage<EPI_PLAIN, true, ASRC_X, KEEP_A2, DEVSEED>(shape_pin<256, 128>(role_ffn1(ch.b)), sm);
+        rowgemm_stage<EPI_PLAIN, false, ASRC_A2, RES_X | KEEP_X, DEVSEED>(shape_pin<128, 256>(role_plain(ch.c)), sm);
+        rowgemm_stage<EPI_FRAG, true, ASRC_X, 0, false>(qkv256(role_qkv(ch.d)), sm);
         return;
     }
     const RowSmem sm = rowchain_carve(smem, ch, false);
@@ -885,6 +912,13 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
         rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(dO128(role_dO(ch.c)), sm);
         return;
     }
+    if (SHAPE == 256 && WIDE) {
+        const RowSmem sm = carve_fixed<MMT_FIX256_LDA, MMT_FIX256_LDF_BWD, false, 0, MMT_FIX256_LDA2>(smem);
+        rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_A2, DEVSEED>(shape_pin<256, 128>(role_bwd_relu(ch.a)), sm);
+        rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(lnbwd256(shape_pin<128, 256>(role_lnbwd(ch.b))), sm);
+        rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(dO256(role_dO(ch.c)), sm);
+        return;
+    }
     const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
     rowgemm_stage<EPI_PLAIN, false, ASRC_GLOBAL, KEEP_A2, DEVSEED>(role_bwd_relu(ch.a), sm);
     rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(role_lnbwd(ch.b), sm);      // dx1 -> global (fp32) and, as the next A tile, LDS (bf16)
@@ -908,6 +942,16 @@ __global__ __launch_bounds__(MMT_RTHREADS, (MMT_ROWS == 16 || MMT_RTHREADS == 51
         rowgemm_stage<EPI_PLAIN, false, ASRC_AS, KEEP_A2, DEVSEED>(shape_pin<128, 128>(role_bwd_relu(ch.b)), sm);
         rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(shape_pin<128, 128>(role_lnbwd(ch.c)), sm);
         rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(dO128(role_dO(ch.d)), sm);
+        return;
+    }
+    if (SHAPE == 256 && WIDE) {
+        const RowSmem sm = carve_fixed<MMT_FIX256_LDA_BND, MMT_FIX256_LDF_BWD, false, 0, MMT_FIX256_LDA2>(smem);
+        RowGemmParams a = lnbwd256(shape_pin<768, 256>(role_lnbwd(ch.a)));
+        a.kchunk = 512;
+        rowgemm_stage<EPI_LNBWD, false, ASRC_GLOBAL, KEEP_AS, DEVSEED, WIDE>(a, sm);
+        rowgemm_stage<EPI_PLAIN, false, ASRC_AS, KEEP_A2, DEVSEED>(shape_pin<256, 128>(role_bwd_relu(ch.b)), sm);
+        rowgemm_stage<EPI_LNBWD, false, ASRC_A2, KEEP_AS, DEVSEED, WIDE>(lnbwd256(shape_pin<128, 256>(role_lnbwd(ch.c))), sm);
+        rowgemm_stage<EPI_FRAG, false, ASRC_AS, 0, false>(dO256(role_dO(ch.d)), sm);
         return;
     }
     const RowSmem sm = rowchain_carve(smem, ch, !WIDE);
