@@ -193,26 +193,42 @@ class Runner:
         from multimodal_transformer_amd import parallel
         self.fwd_bwd, self.params, self.world, self.parallel = fwd_bwd, params, world, parallel
         self.graph, self.launch = None, "eager"
+        self.exchange = "none" if world == 1 else "eager"       # where the gradient all-reduce runs: behind the graph, or as a node of it
         for _ in range(max(1, warmup)):
             self.eager()
         torch.cuda.synchronize()
         if use_graph:
-            try:
-                s = torch.cuda.Stream()
-                s.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(s):
-                    for _ in range(2):
+            import torch.distributed as dist
+            # With RCCL the collective is captured as a node of the step's graph (it starts the moment the finalize kernel ends and costs no
+            # launch of its own); the gloo rehearsal and any failure to capture it keep it behind the replay.
+            # Opt-in (MMT_BENCH_CAPTURE_ALLREDUCE=1): capturing it was verified with a one-rank RCCL group on the GPU box
+            # (tools/probe_graph_allreduce.py); no multi-GPU node was available to verify it at N > 1.
+            with_exchange = (world > 1 and dist.is_initialized() and dist.get_backend() == "nccl"
+                             and os.environ.get("MMT_BENCH_CAPTURE_ALLREDUCE") == "1")
+            for attempt in ((True, False) if with_exchange else (False,)):
+                try:
+                    s = torch.cuda.Stream()
+                    s.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(s):
+                        for _ in range(2):
+                            fwd_bwd()
+                            if attempt:
+                                self.parallel.allreduce_gradients(self.params)
+                    torch.cuda.current_stream().wait_stream(s)
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local" if attempt else "global"):
                         fwd_bwd()
-                torch.cuda.current_stream().wait_stream(s)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    fwd_bwd()
-                self.graph, self.launch = g, "hipgraph"
-            except Exception as e:  # noqa: BLE001
-                print("graph capture failed (%s); falling back to eager launches" % str(e).splitlines()[0], file=sys.stderr)
-                self.graph = None
-                torch.cuda.synchronize()
+                        if attempt:
+                            self.parallel.allreduce_gradients(self.params)
+                    self.graph, self.launch = g, "hipgraph"
+                    if attempt:
+                        self.exchange = "captured"
+                    break
+                except Exception as e:  # noqa: BLE001
+                    print("graph capture%s failed (%s)" % (" with the all-reduce" if attempt else "", str(e).splitlines()[0]), file=sys.stderr)
+                    self.graph = None
+                    torch.cuda.synchronize()
         for _ in range(max(1, warmup)):
             self.step()
         torch.cuda.synchronize()
@@ -224,7 +240,8 @@ class Runner:
     def step(self):
         if self.graph is not None:
             self.graph.replay()
-            self.parallel.allreduce_gradients(self.params)
+            if self.exchange != "captured":
+                self.parallel.allreduce_gradients(self.params)
         else:
             self.eager()
 
@@ -587,6 +604,7 @@ def main():
         }
         if ar_ms is not None:
             out["allreduce_ms"] = round(ar_ms, 4)
+            out["allreduce"] = run.exchange
             out["allreduce_what"] = "mean device time of the gradient SUM all-reduce alone (HIP events around it, after the graph replay)"
         if adam is not None:
             out["with_adam"] = adam
