@@ -82,7 +82,7 @@ def _oracle_mem_scan(apre, chat, Wm, W2, b2):
     return torch.stack(out)
 
 
-@pytest.mark.parametrize("T,B", [(20, 3), (1, 1), (33, 18), (5, 300), (3, 1030), (1000, 2)])
+@pytest.mark.parametrize("T,B", [(20, 3), (1, 1), (33, 18), (5, 300), (4, 257), (3, 1030), (1000, 2)])
 def test_mfn_mem_scan(dev, T, B):
     tag = "mem%d_%d" % (T, B)
     apre = R.gen_normal(tag + "a", (T, B, 128), 17)
