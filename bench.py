@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the attention hot path on MI355X: windows/sec, forward+backward.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N>1 without a launcher: starts its own N ranks through torch.distributed.run)
 
 One step = one TRAIN-MODE (dropout 0.1) forward + MSE loss + backward pass (all input, weight and
 LayerNorm gradients) over one synthetic batch already resident in HBM; with N>1 each rank holds its own
@@ -282,6 +282,37 @@ class Runner:
         return el
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same args>`
+    as a CHILD process (never exec: this process stays a plain relay and makes no GPU call), pass the ranks' stderr through, print the
+    one JSON line rank 0 wrote and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        s_ = ln.strip()
+        if s_.startswith("{") and '"metric"' in s_:
+            line = s_
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the %d ranks ended without a result line" % n, file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -302,8 +333,12 @@ def main():
     rehearsal = os.environ.get("MMT_BENCH_REHEARSAL") == "1"      # developer switch: N ranks on ONE GPU over gloo (code-path check only)
     if rehearsal:
         local_rank = 0
-    if world == 1 and args.gpus > 1:
-        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Called plainly (`python bench.py --gpus N`): start the N ranks ourselves, as fresh children of a process that has
+        # not touched the GPU yet (no HIP call above this line), relay rank 0's JSON line and leave with the launcher's code.
+        sys.exit(spawn_ranks(args.gpus))
+    if world != args.gpus:
+        sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

@@ -422,6 +422,21 @@ static int launch_attn_bwd(int DKP, const bf16* QR, const bf16* KR, const bf16* 
             LAUNCH_CHECK("attn_bwd_diag16_kernel");
             return MMT_OK;
         }
+        static const int babl = getenv("MMT_BABL") ? atoi(getenv("MMT_BABL")) : 0;      // timing-only ablation mask (attn_bwd_diag.h)
+        if (babl && drop.thr16) {
+#define MMT_DIAG_A(a) case a: { static bool c3 = false; \
+            if (!c3) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_diag16_kernel<true, false, a>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); c3 = true; } \
+            hipLaunchKernelGGL((attn_bwd_diag16_kernel<true, false, a>), dim3(D.B * D.h), dim3(MMT_DIAG_THREADS), MMT_DIAG_LDS_BYTES, st, \
+                               QR, KR, VR, dOR, lse, delta, rowmask, scale, dqkv, D.L.NQ, D.h, D.T, D.nt, maskK, drop.scale); } break;
+            switch (babl) {
+                MMT_DIAG_A(1) MMT_DIAG_A(2) MMT_DIAG_A(3) MMT_DIAG_A(4) MMT_DIAG_A(8) MMT_DIAG_A(16) MMT_DIAG_A(32) MMT_DIAG_A(64) MMT_DIAG_A(128)
+                MMT_DIAG_A(192) MMT_DIAG_A(7) MMT_DIAG_A(24) MMT_DIAG_A(28) MMT_DIAG_A(60) MMT_DIAG_A(63) MMT_DIAG_A(255) MMT_DIAG_A(56) MMT_DIAG_A(59)
+                default: return fail(MMT_EINVAL, "MMT_BABL: no such ablation instance");
+            }
+#undef MMT_DIAG_A
+            LAUNCH_CHECK("attn_bwd_diag16_kernel");
+            return MMT_OK;
+        }
 #endif
         if (drop.thr16) MMT_DIAG(true); else MMT_DIAG(false);
 #undef MMT_DIAG

@@ -53,7 +53,10 @@ __host__ inline bool attn_bwd_fused_ok(int DKP, int nt) { return DKP == 16 && nt
 #else
 #define FB_STAMP(n)
 #endif
-template <bool DROP, bool STAMP = false>
+// ABL (diagnostic build only, -DMMT_ABLATIONS; results are WRONG): bit mask of parts left out, to see what each part owns of the launch:
+//   1 the sweep's barriers, 2 the dQ read-add-write, 4 exponentials / dropout / dS, 8 the dV / dK products, 16 patch + dQ product,
+//   32 the next tile's score products, 64 the prologue's global loads, 128 the epilogue's global stores
+template <bool DROP, bool STAMP = false, int ABL = 0>
 __global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
         const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vr, const bf16* __restrict__ dOr,
         const float* __restrict__ lse, const float* __restrict__ delta, const float* __restrict__ rowmask, float scale,
@@ -62,8 +65,8 @@ __global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
     constexpr int DKP = 16, RT = MMT_DIAG_RT_PIECES, TOTAL = MMT_DIAG_QD_PIECES, NW = MMT_DIAG_NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef MMT_ABLATIONS
-    unsigned long long st_kernel = 0;
-    if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_kernel) :: "memory");
+    unsigned long long st_kernel = 0, st_kernel_rt = 0;         // shader-clock ticks and 100 MHz ticks at kernel entry
+    if (STAMP) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_kernel), "=s"(st_kernel_rt) :: "memory");
 #endif
     bf16* const qd0 = reinterpret_cast<bf16*>(smem);                                    // [NW][TOTAL * 8] bf16: every query tile of the head
     const bf16* const zeros = reinterpret_cast<const bf16*>(smem + NW * TOTAL * 16);    // what the padding feature rows of an A fragment read
@@ -100,7 +103,8 @@ __global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
                 else if (q < 128) { src = dOr + offR + (size_t)tile * 32 * DKP + (q - 64) * 8; d = RT + (q - 64) + ((q - 64) >> 5) * (MMT_TR_OCT - 32); }
                 else if (q < 136) { src = lsrc + (size_t)tile * 64 + (q - 128) * 8; d = 2 * RT + (q - 128); lrow[i] = tile * 32 + (q - 128) * 4; }
                 else { src = dsrc + (size_t)tile * 64 + (q - 136) * 8; d = 2 * RT + 8 + (q - 136); }
-                reg[i] = *reinterpret_cast<const bf16x8*>(src);
+                if (!(ABL & 64)) reg[i] = *reinterpret_cast<const bf16x8*>(src);
+                else reg[i] = __builtin_bit_cast(bf16x8, f32x4{-4.f, -4.f, -4.f, -4.f});
                 dst[i] = (tile * TOTAL + d) * 8;
             }
         }
@@ -109,8 +113,10 @@ __global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
             const int ktc = live ? kt : 0;
             const size_t off = ((size_t)(ktc * (DKP / 8) + hh) * 32 + r) * 8;
             char* const mykv = kvl0 + wave * (2 * RT * 16) + (hh * MMT_TR_OCT + r) * 16;
+            if (!(ABL & 64)) {
             *reinterpret_cast<bf16x8*>(mykv) = *reinterpret_cast<const bf16x8*>(Kr + offR + off);
             *reinterpret_cast<bf16x8*>(mykv + RT * 16) = *reinterpret_cast<const bf16x8*>(Vr + offR + off);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -179,6 +185,7 @@ __global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
             if (DROP && NEXT) mw = mrow[(size_t)qn * 64];
             const bf16* const sqc = qd0 + (size_t)qt * TOTAL * 8;               // this tile's Q (then dO, L, delta)
             const float* sd = reinterpret_cast<const float*>(sqc + 2 * RT * 8) + 32;
+            if (!(ABL & 4)) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) s[j] = fast_exp2(s[j]);                // queries >= T: exactly 0 (their L was staged as -inf)
             if (key_tail) {                             // wave-uniform, loop-invariant: only the last key tile's wave pays
@@ -201,6 +208,7 @@ __global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
 #pragma unroll
                 for (int j = 0; j < 16; ++j) dp[j] *= s[j];
             }
+            }
             FB_STAMP(1);                                // exponentials, dropout, dS
             // dV^T / dK^T, and dS into the patch on the way.  A fragments by transposing reads of the resident dO / Q tiles: the lane
             // SUPPLIES the address of query tq of a 4-query block, features 4 tpp .. + 3, and receives feature (lane & 15); fragment slot j
@@ -215,11 +223,14 @@ __global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 pds = pack8(dp, s2);
+                if (!(ABL & 8)) {
                 acc = mfma32(tr_frag2(ado + 128 * s2, ado + 128 * s2 + 64), pack8(s, s2), acc);
                 acc = mfma32(tr_frag2(aq + 128 * s2, aq + 128 * s2 + 64), pds, acc);
+                }
                 // patch row = this lane's key; slots [hh][8 s2 + j] = query acc32_row(8 s2 + j, hh): every aligned group of 4 slots
                 // is 4 consecutive queries, the unit a transposing read hands out
-                *reinterpret_cast<bf16x8*>(patch + r * MMT_DIAG_PATCH_LD + 16 * hh + 8 * s2) = pds;
+                if (!(ABL & 16)) *reinterpret_cast<bf16x8*>(patch + r * MMT_DIAG_PATCH_LD + 16 * hh + 8 * s2) = pds;
+                else acc[s2] += (float)pds[0];
             }
             FB_STAMP(2);                                // packs, dV/dK products, patch writes
             // dQ^T share of this key tile: K^T (features x keys) times dS^T (keys x queries).  K^T fragments by transposing reads of
@@ -231,20 +242,22 @@ __global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
             const bf16* const pb = patch + (8 * hh + tq) * MMT_DIAG_PATCH_LD + 16 * (tpp & 1) + 4 * (2 * (int)up + (tpp >> 1));
 #pragma unroll
             for (int j = 0; j < 16; ++j) dqp[j] = 0.f;
+            if (!(ABL & 16)) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 bfrag = tr_frag2(pb + 16 * MMT_DIAG_PATCH_LD * s2, pb + 16 * MMT_DIAG_PATCH_LD * s2 + 4 * MMT_DIAG_PATCH_LD);
                 dqp = mfma32(tr_frag2(ak + 128 * s2, ak + 128 * s2 + 32), bfrag, dqp);
             }
+            }
             FB_STAMP(3);                                // patch reads, dQ product
-            if (NEXT) scores(qn);                       // the next query tile of this wave: resident, no dependence on the barrier
+            if (NEXT && !(ABL & 32)) scores(qn);        // the next query tile of this wave: resident, no dependence on the barrier
             FB_STAMP(4);                                // next tile's row constants, operand reads and score products
         }
         // step t - 1's additions to the accumulator of query tile qt (by the wave that owns key tile kt + 1) are complete and visible
         // behind this barrier; this wave's own additions of step t are ordered before the next step's barrier by its lgkmcnt(0)
-        if (!FIRST) lds_barrier();
+        if (!FIRST && !(ABL & 1)) lds_barrier();
         FB_STAMP(5);                                    // barrier
-        if (live) {
+        if (live && !(ABL & 2)) {
             float* const slot = dqacc0 + (size_t)qt * (MMT_DIAG_ACC_BYTES / 4) + opaque(lane);
             if (FIRST) {
 #pragma unroll
@@ -257,6 +270,7 @@ __global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
                 for (int j = 0; j < 8; ++j) slot[j * MMT_DIAG_PART_LD] = old[j] + dqp[j];
             }
         }
+        if (ABL & 2) acc[3] += dqp[0];
         FB_STAMP(6);                                    // dQ accumulation
         qt = qn;
     };
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = slot[((i & 3) + 4 * half) * MMT_DIAG_PART_LD + q + 32 * ((i >> 2) & 1)];
-        if (t < T) {
+        if (t < T && !(ABL & 128)) {
             const float rm = rowmask ? rowmask[m0 + t] : 1.f;
             const float sc = (rm == 0.0f) ? 0.f : scale;                        // blanked query rows pass no gradient to Q
             bf16x8 o;
@@ -293,7 +307,8 @@ __global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
     // dK = ln2 * acc rows 16.. (scores are in the log2 domain), dV = acc rows 0..15; column key = r
     const float LN2 = 0.6931471805599453f;
     const int t = kt * 32 + r;
-    if (t < T) {
+    if ((ABL & 128) && acc[0] + acc[3] + acc[9] == 123.456f) dqkv[0] = (bf16)1.f;
+    if (t < T && !(ABL & 128)) {
         const size_t m = (size_t)m0 + t;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -307,9 +322,10 @@ __global__ __launch_bounds__(MMT_DIAG_THREADS) void attn_bwd_diag16_kernel(
     }
 #ifdef MMT_ABLATIONS
     if (STAMP && g_attn_stamps && lane == 0) {          // kernel exit, stores retired
-        unsigned long long t2;
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2) :: "memory");
-        g_attn_stamps[((size_t)blockIdx.x * NW + wave) * 16 + 15] = t2;
+        unsigned long long t2, r2;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2), "=s"(r2) :: "memory");
+        unsigned long long* q = g_attn_stamps + ((size_t)blockIdx.x * NW + wave) * 16;
+        q[15] = t2; q[11] = t2 - st_kernel; q[12] = r2 - st_kernel_rt; q[13] = st_kernel_rt; q[8] = r2;
     }
 #endif
 }

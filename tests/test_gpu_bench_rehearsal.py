@@ -1,11 +1,11 @@
 """The N-rank branch of bench.py — what the driver's 8-GPU scaling run executes — rehearsed on ONE GPU: two fresh rank processes
-(started by the conftest launcher, i.e. not by a process that holds the GPU) run `bench.py --gpus 2` over gloo
+(started by bench.py itself from a plain `python bench.py --gpus 2`, the driver's form of the call; that relay process is a child of
+the conftest launcher, i.e. not of a process that holds the GPU) run the step over gloo
 (MMT_BENCH_REHEARSAL=1: both ranks on cuda:0).  Checks the contract of the JSON line: one line, from rank 0, whole-job value,
 n_gpus, weak scaling, the gradient exchange timed, and that sharding + the SUM all-reduce leave a finite, positive throughput.
 It is a code-path test, not a performance number (the real curve needs the 8-GPU node)."""
 import json
 import os
-import socket
 import sys
 
 import pytest
@@ -15,16 +15,10 @@ import conftest
 pytestmark = pytest.mark.gpu
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 def test_two_rank_bench_line():
     env = dict(os.environ, MMT_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(conftest.ROOT, "bench.py"),
+    # called the way the driver calls it: plain `python bench.py --gpus 2 ...`, no launcher around it — bench.py starts its own ranks
+    cmd = [sys.executable, os.path.join(conftest.ROOT, "bench.py"),
            "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-full-model", "--profile-steps", "0"]
     res = conftest.run_in_fresh_process(cmd, env, timeout=900)
     if res is None:

@@ -47,3 +47,11 @@ wg = full.reshape(B * h, 16, 16)
 pro = wg[:, :, 10].max(axis=1); swp = wg[:, :, 7].max(axis=1); epi = (wg[:, :, 15] - wg[:, :, 14]).max(axis=1)
 print("per workgroup, cycles: prologue median %.0f (max %.0f) | sweep median %.0f (min %.0f max %.0f) | epilogue median %.0f (max %.0f) | sum %.0f"
       % (np.median(pro), pro.max(), np.median(swp), swp.min(), swp.max(), np.median(epi), epi.max(), np.median(pro + swp + epi)))
+# in-kernel clock: s_memtime ticks (shader clock) over s_memrealtime ticks (constant 100 MHz) around the same body, kernel entry -> stores retired
+ck, rt = live[:, 11], live[:, 12]
+ok = rt > 0
+ghz = ck[ok] / rt[ok] * 0.1
+print("in-kernel clock (s_memtime / s_memrealtime x 100 MHz), live waves: median %.3f GHz (5%% %.3f, 95%% %.3f); kernel entry -> exit median %.0f cycles = %.2f us"
+      % (np.median(ghz), np.percentile(ghz, 5), np.percentile(ghz, 95), np.median(ck[ok]), np.median(rt[ok]) / 100.0))
+span = (full[:, 8].max() - full[full[:, 13] > 0][:, 13].min()) / 100.0
+print("first workgroup entry -> last exit of the LAST stamped launch (100 MHz clock, chip-wide): %.2f us" % span)

@@ -16,13 +16,16 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 enum Op { ADD, FMA, MUL, PK_FMA, PK_ADD, PK_MUL, EXP, EXP_F16, LDEXP, CNDMASK_VCC, CNDMASK_SGPR, CVT_PK_BF16, MAX3, MAD_U24, XAD, LSHR,
-          CMP_U16, DPP_MOV, AND, EXP_FMA_MIX, EXP_PKFMA_MIX, PERM, FRACT, CVT_I32, MFMA_EXP_MIX, CMP16_CND, CMPSDWA_CND, MOV_B64, DROP_FIN, SUB, MFMA_ONLY, NOPS };
+          CMP_U16, DPP_MOV, AND, EXP_FMA_MIX, EXP_PKFMA_MIX, PERM, FRACT, CVT_I32, MFMA_EXP_MIX, CMP16_CND, CMPSDWA_CND, MOV_B64, DROP_FIN, SUB, MFMA_ONLY,
+          PK_LSHL16, PK_ASHR16, PERMSWAP, DOT2C_BF16, BFE_I32, MOV_B32, PK_MUL_F16, MFMA16_ONLY, PK_MASK3, BFE_AND2, MFMA_C_OTHER, NOPS };
 static const char* const op_names[NOPS] = {
     "v_add_f32", "v_fma_f32", "v_mul_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32", "v_exp_f32", "v_exp_f16", "v_ldexp_f32",
     "v_cndmask_b32 (vcc)", "v_cndmask_b32 (sgpr pair)", "v_cvt_pk_bf16_f32", "v_max3_f32", "v_mad_u32_u24", "v_xad_u32", "v_lshrrev_b32",
     "v_cmp_le_u16 (->vcc)", "v_mov_b32 dpp quad_perm", "v_and_b32", "8 v_exp + 8 v_fma interleaved", "8 v_exp + 8 v_pk_fma interleaved",
     "v_perm_b32", "v_fract_f32", "v_cvt_i32_f32", "1 mfma32x32x16 + 4 v_exp + 8 v_fma",
-    "v_cmp_le_u16 + v_cndmask(vcc) pair", "v_cmp_ge_u32_sdwa + v_cndmask pair", "v_mov_b64", "drop_fin (6 dependent int ops)", "v_sub_f32", "mfma32x32x16 only"};
+    "v_cmp_le_u16 + v_cndmask(vcc) pair", "v_cmp_ge_u32_sdwa + v_cndmask pair", "v_mov_b64", "drop_fin (6 dependent int ops)", "v_sub_f32", "mfma32x32x16 only",
+    "v_pk_lshlrev_b16", "v_pk_ashrrev_i16", "v_permlane32_swap_b32", "v_dot2c_f32_bf16", "v_bfe_i32", "v_mov_b32", "v_pk_mul_f16", "mfma16x16x32 only",
+    "pair mask: pk_lshl16 + pk_ashr16 + and (x8 = 24 instr)", "score mask: bfe_i32 + and (x8 = 16 instr)", "mfma32x32x16, C = other registers"};
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -115,6 +118,43 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* out, int iters)
         else if (OP == MFMA_ONLY) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
         }
+        else if (OP == PK_LSHL16) R16(asm volatile("v_pk_lshlrev_b16 %0, 1, %0" : "+v"(r[i])))
+        else if (OP == PK_ASHR16) R16(asm volatile("v_pk_ashrrev_i16 %0, 15, %0" : "+v"(r[i])))
+        else if (OP == PERMSWAP) {
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(r[i]), "+v"(r[i + 1]));
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(r[i]), "+v"(r[i + 1]));
+            }
+        }
+        else if (OP == DOT2C_BF16) R16(asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(r[i]) : "v"(k), "v"(z)))
+        else if (OP == BFE_I32) R16(asm volatile("v_bfe_i32 %0, %0, 3, 1" : "+v"(r[i])))
+        else if (OP == MOV_B32) R16(asm volatile("v_mov_b32 %0, %1" : "=v"(r[i]) : "v"(k)))
+        else if (OP == PK_MUL_F16) R16(asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(r[i]) : "v"(k)))
+        else if (OP == MFMA16_ONLY) {
+            typedef float f32x4_ __attribute__((ext_vector_type(4)));
+            f32x4_ a4 = {acc[0], acc[1], acc[2], acc[3]};
+            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, a4, 0, 0, 0);
+            acc[0] = a4[0]; acc[1] = a4[1]; acc[2] = a4[2]; acc[3] = a4[3];
+        }
+        else if (OP == PK_MASK3) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                asm volatile("v_pk_lshlrev_b16 %1, 3, %2\n\tv_pk_ashrrev_i16 %1, 15, %1\n\tv_and_b32 %0, %0, %1" : "+v"(r[i]), "+v"(r[8 + i]) : "v"(k));
+        }
+        else if (OP == BFE_AND2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                asm volatile("v_bfe_i32 %1, %2, 3, 1\n\tv_and_b32 %0, %0, %1" : "+v"(r[i]), "+v"(r[8 + i]) : "v"(k));
+        }
+        else if (OP == MFMA_C_OTHER) {
+            f32x16 cc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) cc[i] = k;
+            f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, cc, 0, 0, 0);
+            asm volatile("" : "+v"(d));
+            r[0] += d[0];
+        }
         else if (OP == MFMA_EXP_MIX) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
 #pragma unroll
@@ -135,7 +175,7 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* out, int iters)
 template <int OP>
 static void run(unsigned long long* dbuf, int cus) {
     const int iters = 4000;
-    const int per_iter = (OP == MFMA_EXP_MIX) ? 13 : (OP == MFMA_ONLY ? 1 : 16);
+    const int per_iter = (OP == MFMA_EXP_MIX) ? 13 : ((OP == MFMA_ONLY || OP == MFMA16_ONLY || OP == MFMA_C_OTHER) ? 1 : (OP == PK_MASK3 ? 24 : 16));
     printf("%-36s", op_names[OP]);
     for (int w : {1, 2, 4}) {
         const int blocks = cus * w, waves = blocks * 4;
@@ -185,5 +225,7 @@ int main() {
     run<CMP_U16>(dbuf, cus); run<DPP_MOV>(dbuf, cus); run<AND>(dbuf, cus); run<EXP_FMA_MIX>(dbuf, cus); run<EXP_PKFMA_MIX>(dbuf, cus);
     run<PERM>(dbuf, cus); run<FRACT>(dbuf, cus); run<CVT_I32>(dbuf, cus); run<MFMA_EXP_MIX>(dbuf, cus);
     run<CMP16_CND>(dbuf, cus); run<CMPSDWA_CND>(dbuf, cus); run<MOV_B64>(dbuf, cus); run<DROP_FIN>(dbuf, cus); run<SUB>(dbuf, cus); run<MFMA_ONLY>(dbuf, cus);
+    run<PK_LSHL16>(dbuf, cus); run<PK_ASHR16>(dbuf, cus); run<PERMSWAP>(dbuf, cus); run<DOT2C_BF16>(dbuf, cus); run<BFE_I32>(dbuf, cus); run<MOV_B32>(dbuf, cus);
+    run<PK_MUL_F16>(dbuf, cus); run<MFMA16_ONLY>(dbuf, cus); run<PK_MASK3>(dbuf, cus); run<BFE_AND2>(dbuf, cus); run<MFMA_C_OTHER>(dbuf, cus);
     return 0;
 }
