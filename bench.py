@@ -113,8 +113,8 @@ def pmc_traffic(site, train, cfg):
     import glob
     if site not in SITE_KERNELS:
         return None, "no counter mapping for this launch site"
-    sha, why = kernel_source_sha(), "no profiles/r*_pmc_per_kernel.json"
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_kernel.json")), reverse=True):
+    sha, why = kernel_source_sha(), "no profiles/r*_pmc_per_kernel*.json"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_kernel*.json")), reverse=True):
         try:
             with open(path) as fh:
                 tab = json.load(fh)
@@ -133,6 +133,44 @@ def pmc_traffic(site, train, cfg):
                 return int(v["hbm_bytes_per_launch"]), "%s (%s)" % (rel, k)
         why = "%s has no entry for %s" % (rel, pref)
     return None, why
+
+
+def roofline_of(prof, nsteps, M, T, d, f, N, train, cfg, top=12):
+    """{site: (total_ms, launches)} of `nsteps` profiled steps -> (kernel_ms_per_step, roofline block of the dominant kernel).
+    `cfg`: the WORKLOADS entry whose counter table (profiles/) holds this kernel at this shape."""
+    kernel_ms = {k: round(v[0] / nsteps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:top]}
+    name, (tot_ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
+    avg_s = tot_ms / cnt * 1e-3
+    fl = site_flops_per_launch(name, M, T, d, f, N)
+    ach = fl / avg_s / 1e12 if avg_s > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(name, train, cfg)
+    roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_src,
+            "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": cnt // nsteps, "flops_per_launch": fl,
+            "share_of_kernel_time": round(tot_ms / sum(v[0] for v in prof.values()), 3)}
+    return kernel_ms, roof
+
+
+def profiled(step, nsteps):
+    """per-kernel HIP-event times of `nsteps` eager calls of `step`, modality streams serialised (an event pair only times its own stream)"""
+    from multimodal_transformer_amd import _lib
+    prev = os.environ.get("MMT_MODALITY_STREAMS")
+    os.environ["MMT_MODALITY_STREAMS"] = "0"
+    try:
+        step()
+        torch.cuda.synchronize()
+        _lib.profile(True)
+        for _ in range(nsteps):
+            step()
+        torch.cuda.synchronize()
+        prof = _lib.profile_collect()
+        _lib.profile(False)
+    finally:
+        if prev is None:
+            os.environ.pop("MMT_MODALITY_STREAMS", None)
+        else:
+            os.environ["MMT_MODALITY_STREAMS"] = prev
+    return prof
 
 
 def make_encoder(cfg):
@@ -427,17 +465,7 @@ def main():
         torch.cuda.synchronize()
         prof = _lib.profile_collect()
         _lib.profile(False)
-        kernel_ms = {k: round(v[0] / args.profile_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
-        name, (tot_ms, cnt) = max(prof.items(), key=lambda kv: kv[1][0])
-        avg_s = tot_ms / cnt * 1e-3
-        fl = site_flops_per_launch(name, M, T, d, f, N)
-        ach = fl / avg_s / 1e12 if avg_s > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(name, train, cfg)
-        roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                    "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": cnt // args.profile_steps,
-                    "flops_per_launch": fl,
-                    "share_of_kernel_time": round(tot_ms / sum(v[0] for v in prof.values()), 3)}
+        kernel_ms, roofline = roofline_of(prof, args.profile_steps, M, T, d, f, N, train, cfg, top=99)
 
     # ---- whole SFT sequence model, same batch shape (N=1 only)
     full = None
@@ -547,6 +575,11 @@ def main():
         mft = {"model": "MultiTransformer(acoustic 88, image 256, linguistic 300 -> 256): 3 embeds + 3 encoder stacks (d=256, h=8, N=6) "
                         "on concurrent streams + MFN gate; T=300, 32 sequences (configs[2])",
                "value": round(Bm * Tm * nst2 / el2, 1), "unit": "windows/s", "ms_per_step": round(1e3 * el2 / nst2, 4), "launch": mrun2.launch}
+        fpw3 = 3 * 3 * 6 * flops_per_window_layer_fwd(256, Tm, 128) + 3 * 1.35e6                  # three stacks + MFN gate
+        mft["algorithmic_mflop_per_window"] = round(fpw3 / 1e6, 2)
+        mft["step_mfma_frac"] = round(mft["value"] * fpw3 / (MFMA_BF16_PEAK_TFLOPS * 1e12), 5)
+        if args.profile_steps > 0:          # per-kernel times (modality streams serialised); a launch covers ONE modality's stack
+            mft["kernel_ms_per_step"], mft["roofline"] = roofline_of(profiled(mft_step, 2), 2, Bm * Tm, Tm, 256, 128, 6, train, WORKLOADS["C3e"])
 
     # ---- configs[3] at its full batch (256 sequences) on one GPU
     full_batch = None
@@ -615,6 +648,8 @@ def main():
                 "value": round(v4, 1), "unit": "windows/s", "ms_per_step": round(1e3 * el4 / n4, 4), "launch": r4.launch,
                 "algorithmic_mflop_per_window": round(fpw4 / 1e6, 2),
                 "step_mfma_frac": round(v4 * fpw4 / (MFMA_BF16_PEAK_TFLOPS * 1e12), 5)}
+        if args.profile_steps > 0:
+            mft4["kernel_ms_per_step"], mft4["roofline"] = roofline_of(profiled(mft4_step, 2), 2, B4 * T4, T4, 256, 128, 6, train, WORKLOADS["C5e"])
         del x4, m4, r4
         torch.cuda.empty_cache()
 

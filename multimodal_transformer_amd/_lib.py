@@ -322,6 +322,14 @@ class DeviceSeed:
         return self.state.data_ptr()
 
 
+def canonical_device(device):
+    """torch.device with its index filled in: `torch.device("cuda")`, "cuda" and `cuda:0` name the same device, but compare unequal"""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 def _host_seed(device, site):
     rank = 0
     try:
@@ -354,18 +362,21 @@ def next_dropout_seed(device, site, holder=None, index=0):
     During hipGraph capture (or with MMT_DEVICE_SEED=1): the module's ``DeviceSeed`` — a seed in device memory that the captured
     kernels read and advance, so every REPLAY draws new masks.  It is created at the module's first eager train-mode call (seeded
     from the generator as above); capturing a module that never ran eagerly raises (a warm-up step always precedes a capture)."""
+    device = canonical_device(device)
     capturing = device.type == "cuda" and torch.cuda.is_current_stream_capturing()
     if os.environ.get("MMT_DEVICE_SEED") == "0":         # developer switch: by-value seeds even under capture (frozen at capture, as in round 2)
         holder = None
     if holder is not None:
-        seeds = holder.__dict__.setdefault("_dev_seeds", {})      # one state per concurrent piece (`index`: sub-batch stream) of the module
-        ds = seeds.get(index)
-        if ds is None or ds.state.device != device:
+        # one state per dropout site of the module AND per concurrent piece of it (`index`: sub-batch stream): two sites that shared a
+        # state word would be correct only while their launches happen to sit on one stream
+        seeds = holder.__dict__.setdefault("_dev_seeds", {})
+        ds = seeds.get((site, index))
+        if ds is None or canonical_device(ds.state.device) != device:
             if capturing:
                 raise RuntimeError("hipGraph capture of a train-mode %s before its first eager call: run one warm-up step so that its "
                                    "device-resident dropout seed exists" % type(holder).__name__)
             ds = DeviceSeed(device, _host_seed(device, mix64(site, index)))
-            seeds[index] = ds
+            seeds[(site, index)] = ds
             if index == 0:
                 holder.__dict__["_dev_seed"] = ds
         if capturing or os.environ.get("MMT_DEVICE_SEED") == "1":

@@ -187,6 +187,9 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = 0.f;
     float mrun = 0.f, lrun = 0.f;
+    f32x16 mneg;                                        // -mrun in every register: the accumulator init of the score product
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mneg[i] = 0.f;
 
     // The tile body is instantiated twice: TAIL = false for the hot loop (no conditional code between an MFMA and the
     // consumers of its result: hipcc's hazard recognizer counts a skippable block's instructions as MFMA->VALU wait
@@ -206,11 +209,22 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
         if (!TAIL) stg.load(kt + 1);                    // next tile in flight behind this tile's arithmetic
         const bf16* sk = stage[kt & 1];
         const bf16* sv = vpad ? zeros : sk + PK * 8 + voff;
+        // S' - m straight out of the MFMA: the accumulator init is a register set that holds -m for the whole sweep and is rewritten
+        // only when the reference moves (round 3 splatted -m into the accumulator before every tile: 8 v_mov_b64 of ~100 vector
+        // instructions per tile)
         f32x16 s;
-        fill16(s, (kt == 0) ? 0.f : -mrun);
+        if constexpr (KS == 1) {
+            // written as asm because hipcc only knows the tied form (vdst = srcC) of an MFMA on VGPRs and would copy mneg into s first;
+            // the trailing s_nop are the wait states between an 8-pass MFMA and a vector instruction that reads its result, which the
+            // hazard recognizer cannot add for an asm statement
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sk + (hh * 32 + r) * 8);
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3\n\ts_nop 11" : "=&v"(s) : "v"(kf), "v"(qf[0]), "v"(mneg));
+        } else {
+            s = mfma32(*reinterpret_cast<const bf16x8*>(sk + (hh * 32 + r) * 8), qf[0], mneg);
 #pragma unroll
-        for (int ss = 0; ss < KS; ++ss)
-            s = mfma32(*reinterpret_cast<const bf16x8*>(sk + ((2 * ss + hh) * 32 + r) * 8), qf[ss], s);
+            for (int ss = 1; ss < KS; ++ss)
+                s = mfma32(*reinterpret_cast<const bf16x8*>(sk + ((2 * ss + hh) * 32 + r) * 8), qf[ss], s);
+        }
         if (TAIL) {                                     // keys >= T do not exist
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[i] = (kt * 32 + acc32_row(i, hh) < T) ? s[i] : -INFINITY;
@@ -221,18 +235,19 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
         tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
         for (int i = 3; i < 15; i += 2) tmax = fmaxf(fmaxf(tmax, s[i]), s[i + 1]);
-        tmax = fmaxf(tmax, s[15]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));      // finite: every tile holds >= 1 real key in one of the halves
+        tmax = fmaxf(tmax, s[15]);                      // over this lane's 16 keys; the other half of the wave holds the query's other 16
         }
-        ATT_STAMP(0);                                   // K fragment read, QK^T, tile maximum, lane exchange
-        if (ABL != 1 && (kt == 0 || __any(tmax > MMT_RESCALE_THR))) {
+        ATT_STAMP(0);                                   // K fragment read, QK^T, tile maximum
+        if (ABL != 1 && (kt == 0 || __any(tmax > MMT_RESCALE_THR))) {      // __any looks at both halves: no exchange on the common path
             // move the reference to the new running max (first tile: from 0 to the tile max, with o = l = 0)
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));  // finite: every tile holds >= 1 real key in one of the halves
             const float dlt = (kt == 0) ? tmax : fmaxf(tmax, 0.f);
             const float alpha = fast_exp2(-dlt);
             mrun += dlt;
             lrun *= alpha;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o[i] *= alpha; s[i] -= dlt; }
+            fill16(mneg, -mrun);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = (ABL == 2) ? s[i] * 0.01f : fast_exp2(s[i]);

@@ -175,12 +175,22 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     constexpr int PFD = rowgemm_pfd<EPI, ASRC, KEEP, WIDE>();
     bf16x8 wf[PFD][2][MMT_WNT];                                   // [slot][k half: +0 / +32][16-column tile of the wave]
     auto w_load = [&](int slot, int nb, int kb) {                 // slot and the guard are compile-time / wave-uniform
+#ifdef MMT_ABL_WCONST   // timing-only ablation (results are WRONG): every W fragment from the same 2 KB, i.e. from the CU's L1 — an upper bound on what
+        // weights held in LDS by a persistent workgroup could save on the L2 -> CU fragment fetches
+        const bf16* wr = p.W + (size_t)l15 * KP + 8 * lq; (void)nb; (void)kb;
+#pragma unroll
+        for (int b = 0; b < MMT_WNT; ++b) {
+            wf[slot][0][b] = *reinterpret_cast<const bf16x8*>(wr);
+            wf[slot][1][b] = *reinterpret_cast<const bf16x8*>(wr + 32);
+        }
+#else
         const bf16* wr = p.W + (size_t)(nb + l15) * KP + 8 * lq + kb;
 #pragma unroll
         for (int b = 0; b < MMT_WNT; ++b) {
             wf[slot][0][b] = *reinterpret_cast<const bf16x8*>(wr + (size_t)16 * b * KP);
             wf[slot][1][b] = *reinterpret_cast<const bf16x8*>(wr + (size_t)16 * b * KP + 32);
         }
+#endif
     };
     auto w_prime = [&](int nb) {
 #pragma unroll

@@ -41,12 +41,14 @@ def _row_chunks(B, k):
     return out
 
 
-def _chunk_seed(seed, i):
+def _chunk_seed(seed, i, nsplit=1):
     if isinstance(seed, (list, tuple)):
         return seed[i]
-    if i == 0 or isinstance(seed, _lib.DeviceSeed):
+    if isinstance(seed, _lib.DeviceSeed):
+        if nsplit > 1:          # seed_advance_kernel reads and writes the state word: sub-batches on concurrent streams need one each
+            raise ValueError("encoder_stack: %d sub-batch streams need a list of %d DeviceSeeds, got one" % (nsplit, nsplit))
         return seed
-    return _lib.mix64(seed, i)
+    return seed if i == 0 else _lib.mix64(seed, i)
 
 
 class _EncoderStackFn(torch.autograd.Function):
@@ -75,7 +77,7 @@ class _EncoderStackFn(torch.autograd.Function):
                 if nbytes == 0:
                     _lib.check(lib.mmt_encoder_forward(None, None, None, None, None, 0, Bi, T, d, h, d_ff, n_layers, eps, 0.0, 0, None))
                 ws = _lib.POOL.get(nbytes, x_.device, tag=("encoder", Bi, T, d, h, d_ff, n_layers, train))
-                sd = _chunk_seed(seed, i)
+                sd = _chunk_seed(seed, i, len(chunks))
                 xp, mp, yp = _lib.ptr(x_) + 4 * b0 * T * d, _lib.ptr(m_) + 4 * b0 * T, _lib.ptr(y) + 4 * b0 * T * d
                 if isinstance(sd, _lib.DeviceSeed):  # device-resident seed: read and advanced by the launch itself (hipGraph replays)
                     _lib.check(lib.mmt_encoder_forward_devseed(xp, mp, _lib.ptr(p_), yp, _lib.ptr(ws), nbytes,

@@ -164,17 +164,12 @@ def test_default_model_under_hipgraph_replay(dev):
     for xi in xs:                                      # eager references (also the warm-up a capture needs)
         x.copy_(xi)
         y_ref = step().detach().clone()                # (no reference to the autograd graph may survive: its AccumulateGrad nodes
-        refs.append((y_ref, params[0].grad.detach().clone()))      #  would stay bound to this stream and break the capture below)
+        refs.append((y_ref, params[0].grad.detach().clone()))      #  would stay bound to this stream; capture_step below checks that)
     F.check_device_errors()
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        step()
-    torch.cuda.current_stream().wait_stream(s)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        y_static = step()
+    # side-stream warm-up + capture through the guard (graphs.capture_step): a reference to an eager step's autograd graph that is
+    # still alive here would be refused with StaleAutogradGraphError instead of ending the process inside hipStreamEndCapture
+    from multimodal_transformer_amd import graphs
+    g, y_static = graphs.capture_step(step, warmup=1)
     for i in (1, 2, 0, 1):
         x.copy_(xs[i])
         g.replay()
@@ -182,6 +177,58 @@ def test_default_model_under_hipgraph_replay(dev):
         assert torch.equal(y_static, refs[i][0]), "replay on input %d" % i
         assert torch.equal(params[0].grad, refs[i][1]), "replay on input %d" % i
     F.check_device_errors()                            # the captured scans fold their error words into a device word that this reads
+
+
+def test_capture_guard_refuses_a_stale_autograd_graph():
+    """Capturing a step while an earlier EAGER step's autograd graph is still referenced forks the default stream into the capture
+    (autograd hands the gradients to AccumulateGrad nodes bound to that stream) and `hipStreamEndCapture` segfaults on ROCm 7.2 — with
+    plain torch, no kernel of this repository involved (tools/repro_capture_stale_autograd.py, case `plain`).  `graphs.capture_step`
+    must find the condition in its side-stream warm-up and raise BEFORE capture_begin (case `guarded`), and must not get in the way
+    of a clean capture (case `clean`).  Child processes: the unguarded case kills its process."""
+    import os
+    import sys
+    import conftest
+    res = conftest.run_in_fresh_process([sys.executable, os.path.join(conftest.ROOT, "tools", "repro_capture_stale_autograd.py")], timeout=600)
+    if res is None:
+        pytest.skip("no launcher process")
+    lines = {l.split()[1]: l for l in res["stdout"].splitlines() if l.startswith("case ")}
+    assert set(lines) == {"clean", "guarded", "plain"}, res["stdout"] + res["stderr"][-2000:]
+    assert "exit code    0" in lines["clean"] and "captured and replayed" in lines["clean"], lines["clean"]
+    assert "exit code    0" in lines["guarded"] and "refused before capture_begin" in lines["guarded"], lines["guarded"]
+    print(lines["plain"])                              # informational: -11 on ROCm 7.2; a later runtime may return an error instead
+
+
+def test_train_mode_capture_with_an_unindexed_device(dev):
+    """`MultiTransformer(..., device=torch.device("cuda"))`: the MFN's device-resident dropout seeds are created at the eager warm-up
+    and must be FOUND again under capture although torch.device("cuda") != the tensors' cuda:0 (round 3 compared the two and raised
+    'before its first eager call' inside the capture)."""
+    from multimodal_transformer_amd import multiTransformer as MT, graphs
+    torch.manual_seed(11)
+    mods, dims = ["acoustic", "linguistic"], {"acoustic": 88, "linguistic": 300}
+    model = MT.MultiTransformer(mods, dims, N=1, device=torch.device("cuda")).train()
+    B, T = 2, 24
+    xin = {m: torch.randn(B, T, dims[m], device=dev) for m in mods}
+    mask = torch.ones(B, T, 1, device=dev)
+    params = [p for p in model.parameters()]
+
+    def step():
+        for p in params:
+            p.grad = None
+        y = model(xin, mask, [T] * B)
+        y.sum().backward()
+        return y
+
+    step()                                             # eager warm-up: creates the seeds (no reference to its graph is kept)
+    n_seeds = len(model.mfn.__dict__.get("_dev_seeds", {}))
+    g, y_static = graphs.capture_step(step, warmup=1)
+    assert len(model.mfn.__dict__["_dev_seeds"]) == n_seeds, "the capture created new seed states instead of finding the warm-up's"
+    g.replay()
+    torch.cuda.synchronize()
+    y1 = y_static.clone()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(y1).all() and torch.isfinite(y_static).all()
+    assert not torch.equal(y1, y_static), "two replays drew the same dropout masks"
 
 
 @pytest.mark.parametrize("d,h,B,T,p", [(128, 8, 3, 300, 0.1), (256, 8, 2, 70, 0.1), (40, 4, 2, 33, 0.0)])

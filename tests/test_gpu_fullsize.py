@@ -7,7 +7,8 @@ so the checks are the size-independent properties of the path plus oracle parity
     32-window tile or which workgroup it landed in;
   * the oracle, run on a few single sequences of the batch (fp32, seconds), matches the full-batch rows of those
     sequences to the stated bf16 tolerances, and so do the input gradients (the loss is a sum over sequences);
-  * weight gradients are additive over a partition of the batch (linearity of the backward pass in the batch);
+  * weight gradients are additive over a partition of the batch (linearity of the backward pass in the batch), and on a sub-batch
+    of four sequences every weight / bias / LayerNorm gradient of all N layers matches the oracle's;
   * blanked (mask == 0) query rows: exact uniform attention, checked through the oracle rows above on ragged lengths;
   * eval mode is deterministic: two runs are bit-identical.
 """
@@ -124,6 +125,40 @@ def test_full_size_properties_and_oracle_rows(dev, name):
         assert r_valid < OUT_RTOL and r_all < OUT_RTOL
         assert ccc >= CCC_MIN
         assert r_dx < RELU_GRAD_RTOL
+
+    # WEIGHT gradients against the oracle (the additivity check above compares the kernels with themselves): the full-length, the
+    # ragged, the 7 %-length and the one-window sequence as one sub-batch through both — all N layers' weight, bias and LayerNorm
+    # gradients, tensor by tensor (wgrad_kernel's window splits + encoder_finalize_kernel's fixed-order sums at T = 300 / 500 / 1000)
+    from conftest import grad_close
+    sub = sorted({0, 1, 2, 3 % B})
+    names = [k for k, _ in enc.named_parameters()]
+    po = {k: v.clone().requires_grad_() for k, v in p32.items()}
+    yo = oracle.encoder_stack(po, "", x_c[sub], mask_c[sub], h)
+    (yo * g_c[sub]).sum().backward()
+    _, _, gsub = _run(enc, x[sub].contiguous(), mask[sub].contiguous(), g[sub].contiguous())
+    gsub = gsub.cpu()
+    off, worst = 0, (0.0, "")
+    for k in names:
+        ref = po[k].grad.reshape(-1)
+        got = gsub[off:off + ref.numel()]
+        off += ref.numel()
+        rel = rel_l2(got.numpy(), ref.numpy())
+        if float(ref.norm()) > 1e-3 * ref.numel() ** 0.5 and rel > worst[0]:
+            worst = (rel, k)
+        if k.endswith("self_attn.linears.1.bias"):
+            # the key-projection bias has NO gradient analytically (a constant added to every key shifts a query's scores alike and
+            # softmax ignores it): the oracle returns fp32 round-off, the kernels the column sum of bf16-rounded dK rows.  Bound it by
+            # the scale of its sibling, the query-projection bias gradient of the same layer
+            sib = po[k.replace("linears.1.bias", "linears.0.bias")].grad
+            assert float(got.norm()) <= 3e-2 * float(sib.norm()) + 1e-5, "%s: %s should vanish, has norm %.3e (query bias %.3e)" % (
+                name, k, float(got.norm()), float(sib.norm()))
+            continue
+        assert grad_close(got.numpy(), ref.numpy(), RELU_GRAD_RTOL, atol=2e-4), "%s: weight gradient of %s off by rel_l2 %.3e" % (name, k, rel)
+    assert off == gsub.numel()
+    allref = torch.cat([po[k].grad.reshape(-1) for k in names])
+    r_w = rel_l2(gsub.numpy(), allref.numpy())
+    print("%s weight gradients of sequences %s vs oracle: rel_l2 %.3e over all %d values; worst tensor %s %.3e" % (name, sub, r_w, off, worst[1], worst[0]))
+    assert r_w < RELU_GRAD_RTOL
 
 
 def test_full_size_blank_rows_are_uniform_attention(dev):

@@ -6,11 +6,12 @@
 # default `python3 bench.py` runs once more with the fresh counter table in place (summary/bench_C4.json).
 set -o pipefail
 TAG=${1:-r01}
+WL=${2:-C4}          # bench.py --workload: C4 (headline), C3e / C5e (one modality's encoder stack of the MFT at configs[2] / configs[4])
 REPO=$(pwd)
-OUT=$REPO/gpurun_out/prof_$TAG
+OUT=$REPO/gpurun_out/prof_${TAG}_$WL
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="$REPO/bench.py"
+BENCH="$REPO/bench.py --workload $WL"
 # the headline workload only (--no-full-model drops the whole-model / full-batch / MFT blocks, which launch the same kernels at other
 # sizes and would blur the per-kernel averages the roofline line is checked against)
 echo "== kernel-trace + stats of: python3 bench.py --no-full-model --no-cpu-baseline"
@@ -25,9 +26,11 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GR
 done
 cd $REPO && python3 tools/summarize_profiles.py $OUT || exit 1
 # the summaries in place (on the box), then the default bench line: its roofline.traffic reads the counter table just written
-cp $OUT/summary/kernel_stats.csv profiles/${TAG}_kernel_stats_bench_C4.csv
-cp $OUT/summary/pmc_per_kernel.json profiles/${TAG}_pmc_per_kernel.json
-tail -1 $OUT/bench_under_rocprof.json > profiles/${TAG}_bench_C4_under_rocprofv3.json
-echo "== default bench"
-python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || exit 1
-tail -1 $OUT/bench_default.json > $OUT/summary/bench_C4.json
+cp $OUT/summary/kernel_stats.csv profiles/${TAG}_kernel_stats_bench_$WL.csv
+if [ "$WL" = "C4" ]; then cp $OUT/summary/pmc_per_kernel.json profiles/${TAG}_pmc_per_kernel.json; else cp $OUT/summary/pmc_per_kernel.json profiles/${TAG}_pmc_per_kernel_$WL.json; fi
+tail -1 $OUT/bench_under_rocprof.json > profiles/${TAG}_bench_${WL}_under_rocprofv3.json
+if [ "$WL" = "C4" ]; then
+  echo "== default bench"
+  python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err || exit 1
+  tail -1 $OUT/bench_default.json > $OUT/summary/bench_C4.json
+fi

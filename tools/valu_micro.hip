@@ -177,7 +177,7 @@ static void run(unsigned long long* dbuf, int cus) {
     const int iters = 4000;
     const int per_iter = (OP == MFMA_EXP_MIX) ? 13 : ((OP == MFMA_ONLY || OP == MFMA16_ONLY || OP == MFMA_C_OTHER) ? 1 : (OP == PK_MASK3 ? 24 : 16));
     printf("%-36s", op_names[OP]);
-    for (int w : {1, 2, 4}) {
+    for (int w : {1, 2, 4, 8}) {
         const int blocks = cus * w, waves = blocks * 4;
         for (int rep = 0; rep < 10; ++rep) hipLaunchKernelGGL(probe<OP>, dim3(blocks), dim3(256), 0, 0, dbuf, iters);
         CHECK(hipDeviceSynchronize());
@@ -208,7 +208,7 @@ int main() {
     const int cus = prop.multiProcessorCount;
     printf("device %s, %d CUs, clockRate %d kHz\n", prop.name, cus, prop.clockRate);
     unsigned long long* dbuf;
-    CHECK(hipMalloc(&dbuf, (size_t)cus * 4 * 4 * sizeof(unsigned long long) * 4));
+    CHECK(hipMalloc(&dbuf, (size_t)cus * 8 * 4 * sizeof(unsigned long long) * 4));
     {   // bring the clocks to their loaded steady state: ~2 s of back-to-back launches
         hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
         float ms = 0.f, tot = 0.f;
