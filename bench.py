@@ -245,20 +245,14 @@ class Runner:
                              and os.environ.get("MMT_BENCH_CAPTURE_ALLREDUCE") == "1")
             for attempt in ((True, False) if with_exchange else (False,)):
                 try:
-                    s = torch.cuda.Stream()
-                    s.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(s):
-                        for _ in range(2):
-                            fwd_bwd()
-                            if attempt:
-                                self.parallel.allreduce_gradients(self.params)
-                    torch.cuda.current_stream().wait_stream(s)
-                    torch.cuda.synchronize()
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local" if attempt else "global"):
+                    def captured_step(with_ar=attempt):
                         fwd_bwd()
-                        if attempt:
+                        if with_ar:
                             self.parallel.allreduce_gradients(self.params)
+                    # side-stream warm-up + capture; refuses (before capture_begin) a stale autograd graph of an eager step, which would
+                    # otherwise end the process inside hipStreamEndCapture (multimodal_transformer_amd/graphs.py)
+                    from multimodal_transformer_amd import graphs
+                    g, _ = graphs.capture_step(captured_step, warmup=2, capture_error_mode="thread_local" if attempt else "global")
                     self.graph, self.launch = g, "hipgraph"
                     if attempt:
                         self.exchange = "captured"

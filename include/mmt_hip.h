@@ -163,6 +163,19 @@ int mmt_softmax_mul_backward(const float* dout, const float* att, const float* v
 /* out[c] = sum over `rows` rows of x (row stride ld): gradient of a row that the forward broadcast over the batch. */
 int mmt_colsum(const float* x, float* out, int rows, int cols, int ld, mmt_stream_t stream);
 
+/* Highway combine of the window encoder with the Dropout(0.3) the front-end applies to it.
+ * Replaces `x_gate * x_proj + (1 - x_gate) * x_conv_out` (transformer/SFT/models.py:47-55; MFT / B2-Trans twins) and `self.dropout(...)`
+ * (transformer/SFT/models.py:132-134): out = drop(gate * proj + (1 - gate) * x) over n elements; proj / gate are the outputs of the two
+ * Linear layers (mmt_linear_forward, act 0 / 3).  Dropout stream 3000 of mmt_debug_dropout_mask, index = element.
+ * seed_state: NULL (seed by value) or a device-resident seed as in mmt_encoder_forward_devseed; then `seedblock` (2 uint64 of device
+ * memory) receives the seed of this call and its stream keys, and the backward takes the same block instead of a seed.
+ * backward: g = drop'(dout); dx = g (1 - gate) [the direct path only: add the two Linear layers' input gradients], dproj = g gate,
+ * dgate = g (proj - x) [w.r.t. the gate's OUTPUT: the sigmoid's derivative is mmt_linear_backward's, act 3]. */
+int mmt_highway_forward(const float* x, const float* proj, const float* gate, float* out, size_t n,
+                        float dropout_p, uint64_t seed, uint64_t* seed_state, uint64_t* seedblock, mmt_stream_t stream);
+int mmt_highway_backward(const float* dout, const float* x, const float* proj, const float* gate, float* dx, float* dproj, float* dgate,
+                         size_t n, float dropout_p, uint64_t seed, const uint64_t* seedblock, mmt_stream_t stream);
+
 /* accum[0] |= word[0] on the device, in stream order: keeps a kernel's device error word (mmt_lstm_scan_*: first word of the workspace)
  * beyond the life of its workspace, also inside a captured hipGraph.  Both pointers are device memory. */
 int mmt_error_accumulate(const uint32_t* word, uint32_t* accum, mmt_stream_t stream);

@@ -47,6 +47,8 @@ SIGNATURES = {
     "mmt_softmax_mul_forward": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "mmt_softmax_mul_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "mmt_colsum": (_I, [_P, _P, _I, _I, _I, _P]),
+    "mmt_highway_forward": (_I, [_P, _P, _P, _P, _SZ, _F, _U64, _P, _P, _P]),
+    "mmt_highway_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _SZ, _F, _U64, _P, _P]),
     "mmt_error_accumulate": (_I, [_P, _P, _P]),
     "mmt_lstm_scan_workspace_bytes": (_SZ, [_I]),
     "mmt_lstm_scan_forward": (_I, [_P] * 8 + [_SZ] + [_I] * 3 + [_P]),

@@ -1222,6 +1222,37 @@ extern "C" int mmt_colsum(const float* x, float* out, int rows, int cols, int ld
     return MMT_OK;
 }
 
+// Highway combine + Dropout(0.3) of the window encoder (glue.h)
+extern "C" int mmt_highway_forward(const float* x, const float* proj, const float* gate, float* out, size_t n,
+                                   float dropout_p, uint64_t seed, uint64_t* seed_state, uint64_t* seedblock, mmt_stream_t stream) {
+    if (!x || !proj || !gate || !out) return fail(MMT_EINVAL, "null pointer argument");
+    if (n == 0) return MMT_OK;
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(MMT_EINVAL, "dropout_p %g outside [0, 1)", dropout_p);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool devseed = seed_state != nullptr && dropout_p > 0.f;
+    if (devseed) {
+        if (!seedblock) return fail(MMT_EINVAL, "a device-resident seed needs the 2-word seed block the backward reads");
+        int rc = launch_seed_advance(seed_state, seedblock, MMT_HIGHWAY_STREAM, 1, st);
+        if (rc) return rc;
+    }
+    const DropCfg c = stream_drop(dropout_p, seed, MMT_HIGHWAY_STREAM, devseed, 16, MMT_HIGHWAY_STREAM);
+    hipLaunchKernelGGL(highway_fwd_kernel, dim3(grid_for((n + 1) / 2)), dim3(256), 0, st, x, proj, gate, out, n, c, devseed ? seedblock : nullptr);
+    LAUNCH_CHECK("highway_fwd_kernel");
+    return MMT_OK;
+}
+extern "C" int mmt_highway_backward(const float* dout, const float* x, const float* proj, const float* gate, float* dx, float* dproj, float* dgate,
+                                    size_t n, float dropout_p, uint64_t seed, const uint64_t* seedblock, mmt_stream_t stream) {
+    if (!dout || !x || !proj || !gate || !dx || !dproj || !dgate) return fail(MMT_EINVAL, "null pointer argument");
+    if (n == 0) return MMT_OK;
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(MMT_EINVAL, "dropout_p %g outside [0, 1)", dropout_p);
+    const bool devseed = seedblock != nullptr && dropout_p > 0.f;
+    const DropCfg c = stream_drop(dropout_p, seed, MMT_HIGHWAY_STREAM, devseed, 16, MMT_HIGHWAY_STREAM);
+    hipLaunchKernelGGL(highway_bwd_kernel, dim3(grid_for((n + 1) / 2)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       dout, x, proj, gate, dx, dproj, dgate, n, c, devseed ? seedblock : nullptr);
+    LAUNCH_CHECK("highway_bwd_kernel");
+    return MMT_OK;
+}
+
 // ------------------------------------------------------------------------------------ LSTM scan
 struct LstmWs { unsigned* err; cl_u64* xb; bf16 *Wf, *Wb; size_t xb_bytes; int HP16, HPAD; size_t bytes; };
 #define MMT_SCAN_ERR_BYTES 256            // error block at workspace offset 0 (word 0: exchange time-out of the four-CU scans)

@@ -88,6 +88,42 @@ __global__ __launch_bounds__(256) void softmax_mul_bwd_kernel(const float* __res
     }
 }
 
+// Highway combine of the window encoder + the Dropout(0.3) behind it (transformer/SFT/models.py:47-55, 132-134):
+//   out = drop(gate * proj + (1 - gate) * x)          gate = sigmoid(linear_gate(x)), proj = linear_projection(x): the row GEMMs' outputs
+// and its backward (the mask is regenerated from the same counters: stream MMT_HIGHWAY_STREAM, index = element; nothing is stored):
+//   g = drop'(dout);  dx = g (1 - gate);  dproj = g gate;  dgate = g (proj - x)
+// One index PAIR per thread and step (one hash word decides both elements, common.h); an odd n leaves one single element.
+#define MMT_HIGHWAY_STREAM 3000u
+__global__ __launch_bounds__(256) void highway_fwd_kernel(const float* __restrict__ x, const float* __restrict__ proj, const float* __restrict__ gate,
+                                                          float* __restrict__ out, size_t n, DropCfg c, const uint64_t* __restrict__ seedblock) {
+    c = drop_resolve(c, seedblock);
+    const size_t npair = (n + 1) >> 1;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < npair; q += (size_t)gridDim.x * 256) {
+        const size_t i = 2 * q;
+        const bool two = i + 1 < n;
+        const float x0 = x[i], x1 = two ? x[i + 1] : 0.f, g0 = gate[i], g1 = two ? gate[i + 1] : 0.f;
+        float y0 = fmaf(g0, proj[i] - x0, x0), y1 = two ? fmaf(g1, proj[i + 1] - x1, x1) : 0.f;
+        if (c.thr16) { const uint32_t w = drop_pair(c, i); y0 = drop_lo(c, w, y0); y1 = drop_hi(c, w, y1); }
+        out[i] = y0;
+        if (two) out[i + 1] = y1;
+    }
+}
+__global__ __launch_bounds__(256) void highway_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ proj,
+                                                          const float* __restrict__ gate, float* __restrict__ dx, float* __restrict__ dproj,
+                                                          float* __restrict__ dgate, size_t n, DropCfg c, const uint64_t* __restrict__ seedblock) {
+    c = drop_resolve(c, seedblock);
+    const size_t npair = (n + 1) >> 1;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < npair; q += (size_t)gridDim.x * 256) {
+        const size_t i = 2 * q;
+        const bool two = i + 1 < n;
+        float d0 = dout[i], d1 = two ? dout[i + 1] : 0.f;
+        if (c.thr16) { const uint32_t w = drop_pair(c, i); d0 = drop_lo(c, w, d0); d1 = drop_hi(c, w, d1); }
+        const float g0 = gate[i], x0 = x[i];
+        dx[i] = d0 * (1.f - g0); dproj[i] = d0 * g0; dgate[i] = d0 * (proj[i] - x0);
+        if (two) { const float g1 = gate[i + 1], x1 = x[i + 1]; dx[i + 1] = d1 * (1.f - g1); dproj[i + 1] = d1 * g1; dgate[i + 1] = d1 * (proj[i + 1] - x1); }
+    }
+}
+
 // out[c] = sum_r x[r][c] in a fixed order (rows is small: a batch)
 __global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int cols, int ld) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -340,6 +340,58 @@ def linear(x, weight, bias=None, act=0, rowscale=None, in_dropout=0.0, out_dropo
                            seed if isinstance(seed, _lib.DeviceSeed) else int(seed))
 
 
+class _HighwayFn(torch.autograd.Function):
+    """The Highway layer of the window encoder with the front-end's Dropout(0.3) behind it, as ONE autograd node:
+        out = drop(gate * proj + (1 - gate) * x),  proj = x Wp^T + bp,  gate = sigmoid(x Wg^T + bg)
+    (transformer/SFT/models.py:27-55,132-134).  One node, so that the three gradient paths into x (direct, through proj, through gate) are
+    summed by a copy2d launch instead of by autograd's library adds."""
+
+    @staticmethod
+    def forward(ctx, x, Wp, bp, Wg, bg, p, seed):
+        lib = _lib.load()
+        _lib.require_hip(x, Wp, bp, Wg, bg)
+        x_, Wp_, bp_, Wg_, bg_ = _f32c(x), _f32c(Wp), _f32c(bp), _f32c(Wg), _f32c(bg)
+        proj, wsp, nbp = _raw_linear_fwd(x_, Wp_, bp_)
+        gate, wsg, nbg = _raw_linear_fwd(x_, Wg_, bg_, act=3)
+        out = torch.empty_like(x_)
+        dev_seed = isinstance(seed, _lib.DeviceSeed) and p > 0.0
+        block = torch.empty(2, dtype=torch.int64, device=x_.device) if dev_seed else None       # seed + stream keys of this call, for the backward
+        _lib.check(lib.mmt_highway_forward(_lib.ptr(x_), _lib.ptr(proj), _lib.ptr(gate), _lib.ptr(out), x_.numel(), p,
+                                           0 if dev_seed else int(seed), seed.ptr() if dev_seed else None, _lib.ptr(block), _lib.stream_ptr()))
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x_, Wp_, Wg_, proj, gate, block)
+            ctx.ws = (wsp, nbp, wsg, nbg)
+        else:
+            _lib.POOL.put(wsp); _lib.POOL.put(wsg)
+        ctx.cfg = (p, 0 if dev_seed else int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x_, Wp_, Wg_, proj, gate, block = ctx.saved_tensors
+        p, seed = ctx.cfg
+        wsp, nbp, wsg, nbg = ctx.ws
+        ctx.ws = None
+        d_ = _f32c(dout)
+        dx, dproj, dgate = torch.empty_like(x_), torch.empty_like(x_), torch.empty_like(x_)
+        _lib.check(lib.mmt_highway_backward(_lib.ptr(d_), _lib.ptr(x_), _lib.ptr(proj), _lib.ptr(gate), _lib.ptr(dx), _lib.ptr(dproj), _lib.ptr(dgate),
+                                            x_.numel(), p, seed, _lib.ptr(block), _lib.stream_ptr()))
+        need_x = ctx.needs_input_grad[0]
+        dx1, dWp, dbp = _raw_linear_bwd(dproj, x_, Wp_, None, None, wsp, nbp, need_x, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        dx2, dWg, dbg = _raw_linear_bwd(dgate, x_, Wg_, gate, None, wsg, nbg, need_x, ctx.needs_input_grad[3], ctx.needs_input_grad[4], act=3)
+        if need_x:
+            K = x_.shape[-1]
+            copy2d([_seg(dx, K, x_.numel() // K, K, src=dx1, src_ld=K, src2=dx2, src2_ld=K, acc=True)])        # dx += dx1 + dx2
+        return (dx if need_x else None), dWp, dbp, dWg, dbg, None, None
+
+
+def highway(x, Wp, bp, Wg, bg, dropout_p=0.0, seed=0):
+    """drop(gate * proj + (1 - gate) * x) with proj = x Wp^T + bp, gate = sigmoid(x Wg^T + bg); seed: python int or ``_lib.DeviceSeed``
+    (train-mode dropout: stream 3000 of dropout_mask, index = element)."""
+    return _HighwayFn.apply(x, Wp, bp, Wg, bg, float(dropout_p), seed if isinstance(seed, _lib.DeviceSeed) else int(seed))
+
+
 class _LstmScanFn(torch.autograd.Function):
     """h_all, c_all = scan(gx, W_rec, h0, c0): the recurrent half of an LSTM layer.
 

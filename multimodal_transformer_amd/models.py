@@ -14,7 +14,7 @@ There is no CPU path.
 import torch
 import torch.nn as nn
 
-from . import functional as F_hip
+from . import _lib, functional as F_hip
 from .multiTransformer import (MultiTransformer, NLPTransformer, UniFullTransformer, UniTransformer, _MOD_STREAMS,
                                _hip_device)
 
@@ -28,10 +28,10 @@ class Highway(nn.Module):
         self.linear_projection = nn.Linear(word_embed_size, word_embed_size, bias=True)
         self.linear_gate = nn.Linear(word_embed_size, word_embed_size, bias=True)
 
-    def forward(self, x_conv_out):
-        proj = F_hip.linear(x_conv_out, self.linear_projection.weight, self.linear_projection.bias)
-        gate = F_hip.linear(x_conv_out, self.linear_gate.weight, self.linear_gate.bias, act=3)
-        return torch.addcmul(x_conv_out, gate, proj - x_conv_out)           # gate*proj + (1-gate)*x
+    def forward(self, x_conv_out, dropout_p=0.0, seed=0):
+        """``dropout_p`` / ``seed``: the front-end's Dropout(0.3) on the Highway output (SFT/models.py:132-134), fused into the combine"""
+        return F_hip.highway(x_conv_out, self.linear_projection.weight, self.linear_projection.bias,
+                             self.linear_gate.weight, self.linear_gate.bias, dropout_p, seed)       # drop(gate*proj + (1-gate)*x)
 
 
 class CNN(nn.Module):
@@ -76,13 +76,15 @@ class _FrontEnd(nn.Module):
     def _encode(self, inputs):
         """{mod: (B,T,W,D)} -> {mod: (B,T,F_mod)}: conv+pool, Highway, Dropout(0.3), one stream per modality."""
         outs = {}
+        p = float(self.dropout.p) if self.training else 0.0
         main, streams = _MOD_STREAMS.begin(self.device, len(self.mods))
-        for mod, st in zip(self.mods, streams):
+        for i, (mod, st) in enumerate(zip(self.mods, streams)):
             with torch.cuda.stream(st):
                 x = inputs[mod]
                 B, T, W, D = x.shape
                 e = self.CNN[mod].forward_windows(x.reshape(B * T, W, D))
-                e = self.dropout(self.Highway[mod](e))
+                seed = _lib.next_dropout_seed(x.device, 6, holder=self, index=i) if p > 0.0 else 0      # one seed state per modality stream
+                e = self.Highway[mod](e, p, seed)
                 outs[mod] = e.reshape(B, T, -1)
         _MOD_STREAMS.end(main, streams, list(outs.values()))
         return outs
@@ -106,7 +108,7 @@ class MultiCNNTransformer(_FrontEnd):
     def forward(self, inputs, length, mask=None):
         outs = self._encode(inputs)
         if len(self.mods) > 1:
-            cat = torch.cat([outs[m] for m in self.mods], 2)
+            cat = F_hip.cat_cols([outs[m] for m in self.mods])
             fused = F_hip.linear(cat, self.fusionLayer.weight, self.fusionLayer.bias, act=2)      # tanh, :138
             return self.Transformer(fused, mask, length)
         return self.Transformer(outs[self.mods[0]], mask, length)
@@ -148,5 +150,5 @@ class MultiCNNTransformerB2(_FrontEnd):
     def forward(self, inputs, length, mask=None):
         outs = self._encode(inputs)
         if len(outs) > 1:
-            return self.Transformer(torch.cat([outs[m] for m in self.mods], 2), mask, length)
+            return self.Transformer(F_hip.cat_cols([outs[m] for m in self.mods]), mask, length)
         return self.Transformer(outs[self.mods[0]], mask, length)

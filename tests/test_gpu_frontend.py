@@ -144,6 +144,50 @@ def test_highway_golden(dev):
         assert rel_l2(p.grad.cpu().numpy(), fx["grad:" + n]) < GRAD_RTOL, n
 
 
+@pytest.mark.parametrize("shape", [(12, 256), (7, 44), (1, 4)])
+def test_highway_train_mode_mask_replay(dev, shape):
+    """The front-end's Dropout(0.3) rides in the Highway combine (mmt_highway_forward / _backward, stream 3000): the mask the kernels
+    applied is read back through mmt_debug_dropout_mask and replayed through the oracle, forward and backward (odd element counts: the
+    generator decides index PAIRS, the last element of an odd n stands alone)."""
+    import oracle
+    from multimodal_transformer_amd import models as M, functional as F
+    rows, n = shape
+    hw = M.Highway(n)
+    p32 = _load_named(hw)
+    hw = hw.to(dev)
+    x_c = R.gen_normal("fe_highway_drop:x%d" % n, (rows, n), R.SEED)
+    g_c = R.gen_normal("fe_highway_drop:g%d" % n, (rows, n), R.SEED)
+    x = x_c.to(dev).requires_grad_()
+    pdrop, seed = 0.3, 4242
+    y = hw(x, pdrop, seed)
+    (y * g_c.to(dev)).sum().backward()
+    keep, scale = F.dropout_mask(pdrop, seed, 3000, rows * n, dev)
+    keep = keep.reshape(rows, n).cpu()
+    assert abs(scale - 1.0 / (1.0 - pdrop)) < 1e-3
+    if rows * n >= 1000:
+        assert abs(float(keep.float().mean()) - (1.0 - pdrop)) < 0.05
+    pd = {k: v.double().requires_grad_() for k, v in p32.items()}
+    xd = x_c.double().requires_grad_()
+    ref = oracle.highway(pd, "", xd) * keep.double() * scale
+    (ref * g_c.double()).sum().backward()
+    assert torch.equal(y.detach().cpu() == 0, ~keep | (ref.detach() == 0)), "dropped elements must be exactly zero"
+    assert grad_close_t(y.detach().cpu(), ref.detach(), OUT_RTOL)
+    assert grad_close_t(x.grad.cpu(), xd.grad, GRAD_RTOL)
+    for nme, prm in hw.named_parameters():
+        assert grad_close_t(prm.grad.cpu(), pd[nme].grad, GRAD_RTOL), nme
+    # a second call with another seed draws another mask; the same seed reproduces the first
+    y2 = hw(x.detach(), pdrop, seed + 1)
+    y3 = hw(x.detach(), pdrop, seed)
+    assert torch.equal(y3, y.detach())
+    if rows * n >= 64:
+        assert not torch.equal(y2, y.detach())
+
+
+def grad_close_t(a, b, rtol):
+    from conftest import grad_close
+    return grad_close(a.double().numpy(), b.double().numpy(), rtol, atol=1e-5)
+
+
 @pytest.mark.parametrize("name,cls,mods,extra", [
     ("fe_model_sft", "MultiCNNTransformer", R.MODS_AVL, ()),
     ("fe_model_mft", "MultiCNNTransformerMFT", R.MODS_AVL, (R.FE_EMBED_MFT,)),

@@ -432,7 +432,7 @@ def _library_kernels(names):
     return sorted(set(n for n in names if any(b in n for b in bad)))
 
 
-@pytest.mark.parametrize("which", ["mft", "sft"])
+@pytest.mark.parametrize("which", ["mft", "sft", "raw_sft", "raw_mft"])
 def test_train_step_runs_no_library_kernel(dev, which):
     """One train-mode forward + loss + backward of the whole MFT / SFT sequence model launches hand-written HIP kernels only — no ATen
     element-wise, concatenation or copy kernel, no library GEMM (the MFN gate's softmax(att1) * cStar, the shift of c, the concatenations
@@ -444,7 +444,22 @@ def test_train_step_runs_no_library_kernel(dev, which):
     lengths = [40, 33, 20, 5]
     mask = R.prefix_mask(lengths, T).to(dev)
     tgt = (R.gen_uniform("nolib:t", (B, T, 1), 3) * R.prefix_mask(lengths, T)).to(dev)
-    if which == "mft":
+    raw = which.startswith("raw_")
+    if raw:
+        # raw windows -> valence: the window encoder (CNN k=2 + max-pool + Highway + Dropout(0.3), modality concatenation, fusion layer:
+        # transformer/SFT/models.py:113-142, MFT twin) in front of the sequence model — its Highway combine, dropout and torch.cat were
+        # library kernels until round 4
+        MM = mta().models
+        mods, dims, wl = ["acoustic", "linguistic"], {"acoustic": 88, "linguistic": 300}, {"acoustic": 6, "linguistic": 9}
+        if which == "raw_sft":
+            model = MM.MultiCNNTransformer(mods, dims, device=dev)
+            model.Transformer = MT.NLPTransformer(512, embed_dim=128, h=8, N=2, device=dev)
+        else:
+            model = MM.MultiCNNTransformerMFT(mods, dims, {"acoustic": 88, "linguistic": 300}, device=dev)
+            model.Transformer = MT.MultiTransformer(mods, {"acoustic": 88, "linguistic": 300}, N=2, device=dev)
+        model.train()
+        x = {m: R.gen_normal("nolib:raw:" + m, (B, T, wl[m], dims[m]), 3).to(dev) for m in mods}
+    elif which == "mft":
         model = MT.MultiTransformer(R.MODS_AVL, R.EMBED_AVL, device=dev).train()
         x = {m: R.gen_normal("nolib:" + m, (B, T, R.EMBED_AVL[m]), 3).to(dev) for m in R.MODS_AVL}
     else:
@@ -455,7 +470,7 @@ def test_train_step_runs_no_library_kernel(dev, which):
     def step():
         for p in params:
             p.grad = None
-        F.mse_sum_loss_backward(model(x, mask, lengths), tgt, sum(lengths))
+        F.mse_sum_loss_backward(model(x, lengths, mask) if raw else model(x, mask, lengths), tgt, sum(lengths))
 
     names = _device_kernel_names(step)
     if names is None:

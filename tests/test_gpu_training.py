@@ -168,3 +168,33 @@ def test_flat_adam_state_dict_round_trip(dev):
     opt3 = FlatAdam(copy.deepcopy(twin_t).parameters(), lr=1e-3, weight_decay=1e-2)
     opt3.load_state_dict(copy.deepcopy(opt_t.state_dict()))
     assert all(float(v["step"]) == 5.0 for v in opt3.state_dict()["state"].values())
+
+
+def test_packed_loader_ships_batches_through_pinned_memory(dev, tmp_path):
+    """SURVEY 8f-4: the packed file's loader assembles every batch in page-locked staging buffers and copies it on a stream of its own;
+    what arrives on the device equals the host batches of generate_train_batches (the restatement of generateTrainBatch,
+    transformer/SFT/train.py:74-106) bit for bit, epoch after epoch (the two staging sets are reused while copies are in flight)."""
+    import numpy as np
+    from multimodal_transformer_amd import batching as Bt
+    rng = np.random.RandomState(9)
+    lengths = [int(v) for v in rng.randint(1, 40, size=23)]
+    data = {"acoustic": [rng.randn(L, 4, 8).astype(np.float32) for L in lengths],
+            "image": [rng.randn(L, 3, 16).astype(np.float32) for L in lengths]}
+    target = [rng.rand(L).astype(np.float32) for L in lengths]
+    path = str(tmp_path / "d.mmtpack")
+    Bt.pack_dataset(path, data, target, lengths)
+    ds = Bt.PackedDataset(path)
+    loader = Bt.PackedLoader(ds, batch_size=5, device=dev)
+    assert all(v.is_pinned() for st in loader._stage for v in list(st["data"].values()) + [st["target"], st["mask"]])
+    ref = list(Bt.generate_train_batches(data, target, lengths, batch_size=5))
+    for epoch in range(2):
+        got = []
+        for d, t, m, ls in loader:
+            assert t.device.type == "cuda" and all(v.device.type == "cuda" for v in d.values())
+            got.append(({k: v.clone() for k, v in d.items()}, t.clone(), m.clone(), ls))      # consume on the current stream
+        torch.cuda.synchronize()
+        assert len(got) == len(ref) == 5
+        for (d0, t0, m0, l0), (d1, t1, m1, l1) in zip(ref, got):
+            assert l0 == l1 and torch.equal(t0, t1.cpu()) and torch.equal(m0, m1.cpu())
+            for mod in d0:
+                assert torch.equal(d0[mod], d1[mod].cpu()), (epoch, mod)
