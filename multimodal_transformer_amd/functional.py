@@ -485,6 +485,7 @@ class _ConvPoolFn(torch.autograd.Function):
         ctx.save_for_backward(x_, arg)
         ctx.dims = (N, W, D, F_, nbytes)
         ctx.mark_non_differentiable(arg)
+        ctx.set_materialize_grads(False)        # no zeros tensor for the index output's "gradient" (that would be a library fill kernel)
         return out, arg
 
     @staticmethod
@@ -492,6 +493,8 @@ class _ConvPoolFn(torch.autograd.Function):
         lib = _lib.load()
         x_, arg = ctx.saved_tensors
         N, W, D, F_, nbytes = ctx.dims
+        if dout is None:
+            return None, None, None
         g = _f32c(dout)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
         dw = torch.empty(F_, D, 2, dtype=torch.float32, device=g.device)
