@@ -113,7 +113,7 @@ def pmc_traffic(site, train, cfg):
     import glob
     if site not in SITE_KERNELS:
         return None, "no counter mapping for this launch site"
-    sha, why = kernel_source_sha(), "no profiles/r*_pmc_per_kernel*.json"
+    sha, why = kernel_source_sha(), "no counter table of this workload and mode under profiles/"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_kernel*.json")), reverse=True):
         try:
             with open(path) as fh:
@@ -121,11 +121,11 @@ def pmc_traffic(site, train, cfg):
         except (OSError, ValueError):
             continue
         meta, rel = tab.get("_meta", {}), os.path.relpath(path, ROOT)
-        if meta.get("csrc_sha") != sha:
-            why = "stale: %s was collected on kernel sources %s, running %s" % (rel, meta.get("csrc_sha"), sha)
-            continue
         if meta.get("workload") != cfg["desc"] or bool(meta.get("train")) != bool(train):
-            why = "%s is for another workload / mode" % rel
+            continue                                    # another workload's / mode's table
+        if meta.get("csrc_sha") != sha:
+            if not why.startswith("stale"):             # name the NEWEST table of this workload, not the oldest
+                why = "stale: %s was collected on kernel sources %s, running %s" % (rel, meta.get("csrc_sha"), sha)
             continue
         pref = SITE_KERNELS[site]
         for k, v in tab.items():
