@@ -318,16 +318,15 @@ def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same args>`
     as a CHILD process (never exec: this process stays a plain relay and makes no GPU call), pass the ranks' stderr through, print the
     one JSON line rank 0 wrote and return the launcher's exit code."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):     # a scheduler's presets must not leak into the ranks
+        env.pop(k, None)
+    # --standalone: the launcher picks a free rendezvous port itself (a port found by bind-and-close here could be taken before it is used)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None
     for ln in proc.stdout:
@@ -347,7 +346,7 @@ def spawn_ranks(n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: the launcher's WORLD_SIZE, else 1")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
@@ -359,18 +358,23 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=5, help="extra eager steps with per-kernel HIP-event timing")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Under a launcher (torchrun sets RANK and LOCAL_RANK for every rank) the world size is the launcher's; a WORLD_SIZE that some
+    # scheduler preset for a process that is nobody's rank means nothing.
+    launched = "RANK" in os.environ and "LOCAL_RANK" in os.environ
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
     rehearsal = os.environ.get("MMT_BENCH_REHEARSAL") == "1"      # developer switch: N ranks on ONE GPU over gloo (code-path check only)
     if rehearsal:
         local_rank = 0
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if args.gpus is None:
+        args.gpus = world                                   # `torchrun --nproc-per-node N bench.py` without --gpus
+    if not launched and args.gpus > 1:
         # Called plainly (`python bench.py --gpus N`): start the N ranks ourselves, as fresh children of a process that has
         # not touched the GPU yet (no HIP call above this line), relay rank 0's JSON line and leave with the launcher's code.
         sys.exit(spawn_ranks(args.gpus))
     if world != args.gpus:
-        sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
+        sys.exit("bench.py --gpus %d was started by a launcher with WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

@@ -379,14 +379,24 @@ def next_dropout_seed(device, site, holder=None, index=0):
                                    "device-resident dropout seed exists" % type(holder).__name__)
             ds = DeviceSeed(device, _host_seed(device, mix64(site, index)))
             seeds[(site, index)] = ds
-            if index == 0:
-                holder.__dict__["_dev_seed"] = ds
         if capturing or os.environ.get("MMT_DEVICE_SEED") == "1":
             return ds
     elif capturing:
         _seed_fallback_counter[0] += 1
         return mix64(torch.initial_seed(), (1 << 40) + _seed_fallback_counter[0], site)     # frozen under replay: stand-alone attention() only
     return _host_seed(device, mix64(site, index) if index else site)
+
+
+def device_seed(holder, site=None, index=0):
+    """The ``DeviceSeed`` of one dropout site of a module (sites: 1 encoder stack, 2 / 4 the MFN's gamma and output dropouts, 5 the SFT
+    embedding's input dropout, 6 the window encoder's Dropout(0.3)).  ``site=None`` is accepted only where the module has ONE site."""
+    seeds = holder.__dict__.get("_dev_seeds", {})
+    if site is None:
+        sites = sorted({s for (s, _) in seeds})
+        if len(sites) != 1:
+            raise KeyError("%s has dropout sites %s: name one" % (type(holder).__name__, sites))
+        site = sites[0]
+    return seeds[(site, index)]
 
 
 def profile(on):

@@ -15,6 +15,18 @@ graph is found BEFORE `capture_begin`, where raising is harmless — and refuses
 (a captured hipMemsetAsync and a captured device-to-host copy misbehaving under replay) were the same kind of event: work that a capture
 placed on a stream nobody joined; the library launches kernels only (`zero_fill_kernel`, `error_accumulate_kernel`), so neither can
 occur in a captured step any more.
+
+torch emits that warning through TORCH_WARN_ONCE: once it has fired anywhere in the process — e.g. from an unguarded raw capture of an
+earlier test — a later warm-up would see nothing.  The warm-up therefore runs under `torch.set_warn_always(True)` (restored afterwards),
+which makes every occurrence visible, so the guard does not depend on being the first to see the condition
+(`test_capture_guard_works_repeatedly_in_one_process`).
+
+A stale graph whose AccumulateGrad nodes sit on a SIDE stream (an eager warm-up that itself ran under `torch.cuda.stream(s)`) was
+observed NOT to crash a raw capture (round 4's `test_device_resident_seed_fresh_masks_per_graph_replay` captured that way and emitted
+the warning).  The likely reason: `torch.cuda.graph` captures on a side stream of its own and the engine, at the end of the backward,
+makes the stream that called `backward()` wait for every stream its nodes ran on, so `s` is joined back into the capture before
+`capture_end`; the DEFAULT stream is the one the capture machinery never waits for.  The guard refuses both forms — the surviving one
+still runs gradient accumulation on a foreign stream inside the graph — and no test captures that way any more.
 """
 import warnings
 
@@ -39,6 +51,8 @@ def capture_step(step, warmup=2, graph=None, **graph_kwargs):
     side.wait_stream(torch.cuda.current_stream())
     if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(True)         # torch's default; a caller may have silenced it
+    warn_always = torch.is_warn_always_enabled()
+    torch.set_warn_always(True)                         # TORCH_WARN_ONCE would hide the condition after its first occurrence in the process
     with warnings.catch_warnings():
         warnings.filterwarnings("error", message=r".*AccumulateGrad node's stream does not match.*")
         try:
@@ -53,6 +67,8 @@ def capture_step(step, warmup=2, graph=None, **graph_kwargs):
                 torch.cuda.synchronize()
                 raise StaleAutogradGraphError(_STALE) from e
             raise
+        finally:
+            torch.set_warn_always(warn_always)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = graph if graph is not None else torch.cuda.CUDAGraph()

@@ -1,6 +1,8 @@
 """Oracle: MFN delta-memory attention gate (TEST INFRASTRUCTURE — see oracle/__init__.py).
 
-Restates transformer/MFT/multiTransformer.py:118-248 in eval mode.  The statement here is
+Restates transformer/MFT/multiTransformer.py:118-248.  Dropout (gamma{1,2}_dropout :222-223, out_dropout :245) is taken as explicit
+multipliers (keep / (1 - p), or None = identity = eval mode), so a train-mode pass of the HIP path can be replayed with the masks its
+kernels drew.  The statement here is
 *phase-ordered* (all LSTM steps first, then everything that depends only on the cell
 states, then the memory recurrence, then the per-step read-out) because that is the
 decomposition the HIP path uses; the arithmetic per element is the reference's.
@@ -27,10 +29,12 @@ def _fc(p, name, x):
     return x @ p[name + ".weight"].transpose(0, 1) + p[name + ".bias"]
 
 
-def mfn_gate(p, prefix, inputs, mods):
+def mfn_gate(p, prefix, inputs, mods, gamma_drop=None, out_drop=None):
     """inputs: {mod: (T, B, d_mod)} -> (B, T, 1).  Lines :181-248.
 
     ``mods`` order fixes the concatenation order of the per-modality states (:212-217, :241-243).
+    ``gamma_drop``: (m1, m2), each (T, B, 64): multipliers on relu(gamma1_fc1(both)) and relu(gamma2_fc1(both)) (:222-223).
+    ``out_drop``: (T, B, 64): multiplier on relu(out_fc1(last)) (:245).
     """
     first = inputs[mods[0]]
     T, B = first.shape[0], first.shape[1]
@@ -63,13 +67,20 @@ def mfn_gate(p, prefix, inputs, mods):
     mems = []
     for t in range(T):
         both = torch.cat([attended[t], mem], dim=-1)
-        g1 = torch.sigmoid(_fc(p, prefix + "gamma1_fc2", torch.relu(_fc(p, prefix + "gamma1_fc1", both))))
-        g2 = torch.sigmoid(_fc(p, prefix + "gamma2_fc2", torch.relu(_fc(p, prefix + "gamma2_fc1", both))))
+        u1 = torch.relu(_fc(p, prefix + "gamma1_fc1", both))
+        u2 = torch.relu(_fc(p, prefix + "gamma2_fc1", both))
+        if gamma_drop is not None:
+            u1, u2 = u1 * gamma_drop[0][t], u2 * gamma_drop[1][t]
+        g1 = torch.sigmoid(_fc(p, prefix + "gamma1_fc2", u1))
+        g2 = torch.sigmoid(_fc(p, prefix + "gamma2_fc2", u2))
         mem = g1 * mem + g2 * c_hat[t]
         mems.append(mem)
     mem_all = torch.stack(mems)                                              # (T,B,128)
 
     # phase D — per-step read-out (:238-247)
     last = torch.cat([h_all, mem_all], dim=-1)
-    out = _fc(p, prefix + "out_fc2", torch.relu(_fc(p, prefix + "out_fc1", last)))  # (T,B,1)
+    hid = torch.relu(_fc(p, prefix + "out_fc1", last))
+    if out_drop is not None:
+        hid = hid * out_drop
+    out = _fc(p, prefix + "out_fc2", hid)                                    # (T,B,1)
     return out.permute(1, 0, 2)

@@ -140,6 +140,12 @@ def main():
                extra_full=("mfn.out_fc2.weight", "embed_acoustic.bias", "transformer_image.norm.a_2",
                            "transformer_linguistic.layers.0.sublayer.0.norm.b_2"))
 
+    for name, mods_s, embed_s in R.MFT_SWEEP:                              # transformer/MFT/train.py:538-552
+        m = mft.MultiTransformer(mods_s, embed_s, device=cpu)
+        ins = {md: R.gen_normal(name + ":" + md, (4, 50, embed_s[md]), R.SEED) for md in mods_s}
+        model_case(name, m, ins, lengths, 50,
+                   extra_full=("mfn.out_fc2.weight", "mfn.att1_fc1.weight", "mfn.gamma1_fc1.weight", "embed_acoustic.weight"))
+
     for name, kw in (("model_sft_d128", dict(embed_dim=128, h=8)), ("model_sft_d40", dict(embed_dim=40, h=4)),
                      ("model_sft_default", dict())):
         m = sft.NLPTransformer(512, device=cpu, **kw)

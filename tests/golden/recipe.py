@@ -18,6 +18,14 @@ import torch
 
 MODS_AVL = ["acoustic", "image", "linguistic"]          # transformer/MFT/train.py:541-548 order
 EMBED_AVL = {"acoustic": 88, "image": 256, "linguistic": 300}  # transformer/MFT/train.py:552
+# the other models of the reference's MFT sweep (transformer/MFT/train.py:538-552: VA / AL / VAL x acoustic embed 88 / 44):
+# two-modality gates (2H = 272: see oracle.mfn_ref.HIDDEN) and the 44-wide acoustic embed run through other segment
+# tables and row-GEMM paddings than VAL-88.  (fixture name, modalities in the sweep's order, window_embed_size)
+MFT_SWEEP = [
+    ("model_mft_va88", ["acoustic", "image"], {"acoustic": 88, "image": 256}),
+    ("model_mft_al88", ["acoustic", "linguistic"], {"acoustic": 88, "linguistic": 300}),
+    ("model_mft_val44", ["acoustic", "image", "linguistic"], {"acoustic": 44, "image": 256, "linguistic": 300}),
+]
 
 
 def _gen(tag, seed):

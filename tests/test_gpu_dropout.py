@@ -235,7 +235,7 @@ def test_device_resident_seed_fresh_masks_per_graph_replay(dev):
         xg.grad = None
         y = enc(xg, md)
         (y * gd).sum().backward()
-        out["y"] = y
+        out["y"] = y.detach()                                                 # no reference to the step's autograd graph survives the step
 
     with pytest.raises(RuntimeError, match="warm-up"):                        # a capture needs the seed state to exist beforehand
         fresh = MT.Encoder(MT.EncoderLayer(d, MT.MultiHeadedAttention(h, d), MT.PositionwiseFeedForward(d, R.D_FF, p), p), 1).to(dev).train()
@@ -243,22 +243,14 @@ def test_device_resident_seed_fresh_masks_per_graph_replay(dev):
         with torch.cuda.graph(gtmp):
             fresh(xg.detach(), md)
     torch.cuda.synchronize()
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(2):
-            step()                                                            # eager warm-up: by-value seeds, creates the DeviceSeed
-    torch.cuda.current_stream().wait_stream(s)
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        step()
+    from multimodal_transformer_amd import graphs
+    graph, _ = graphs.capture_step(step, warmup=2)                            # eager side-stream warm-up (by-value seeds, creates the DeviceSeed), then the capture
     results = []
     for _ in range(2):
-        seed = enc._dev_seed.peek()                                           # the seed this replay is going to use
+        seed = mta()._lib.device_seed(enc, 1).peek()                                           # the seed this replay is going to use
         graph.replay()
         torch.cuda.synchronize()
-        assert enc._dev_seed.peek() != seed                                   # the launch advanced it
+        assert mta()._lib.device_seed(enc, 1).peek() != seed                                   # the launch advanced it
         results.append((seed, out["y"].detach().clone(), xg.grad.detach().clone(),
                         torch.cat([q.grad.reshape(-1) for q in enc.flat_parameters()]).clone()))
     assert float((results[0][1] - results[1][1]).abs().max()) > 1e-2          # different masks in the two replays

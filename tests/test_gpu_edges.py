@@ -182,9 +182,9 @@ def test_default_model_under_hipgraph_replay(dev):
 def test_capture_guard_refuses_a_stale_autograd_graph():
     """Capturing a step while an earlier EAGER step's autograd graph is still referenced forks the default stream into the capture
     (autograd hands the gradients to AccumulateGrad nodes bound to that stream) and `hipStreamEndCapture` segfaults on ROCm 7.2 — with
-    plain torch, no kernel of this repository involved (tools/repro_capture_stale_autograd.py, case `plain`).  `graphs.capture_step`
-    must find the condition in its side-stream warm-up and raise BEFORE capture_begin (case `guarded`), and must not get in the way
-    of a clean capture (case `clean`).  Child processes: the unguarded case kills its process."""
+    plain torch, no kernel of this repository involved (tools/repro_capture_stale_autograd.py --with-plain, manual use only: the
+    routine suite does not provoke a known crash on a shared GPU).  `graphs.capture_step` must find the condition in its side-stream
+    warm-up and raise BEFORE capture_begin (case `guarded`), and must not get in the way of a clean capture (case `clean`)."""
     import os
     import sys
     import conftest
@@ -192,10 +192,47 @@ def test_capture_guard_refuses_a_stale_autograd_graph():
     if res is None:
         pytest.skip("no launcher process")
     lines = {l.split()[1]: l for l in res["stdout"].splitlines() if l.startswith("case ")}
-    assert set(lines) == {"clean", "guarded", "plain"}, res["stdout"] + res["stderr"][-2000:]
+    assert set(lines) == {"clean", "guarded"}, res["stdout"] + res["stderr"][-2000:]
     assert "exit code    0" in lines["clean"] and "captured and replayed" in lines["clean"], lines["clean"]
     assert "exit code    0" in lines["guarded"] and "refused before capture_begin" in lines["guarded"], lines["guarded"]
-    print(lines["plain"])                              # informational: -11 on ROCm 7.2; a later runtime may return an error instead
+
+
+def test_capture_guard_works_repeatedly_in_one_process(dev):
+    """torch emits the AccumulateGrad stream-mismatch warning through TORCH_WARN_ONCE.  The guard must not depend on seeing its first
+    occurrence: (1) let the warning fire UNGUARDED (an eager backward on a side stream over nodes bound to the default stream — no
+    capture involved, nothing crashes), (2) the guard must still refuse a stale graph, (3) and refuse it a second time, (4) and a clean
+    capture must still go through afterwards."""
+    import warnings
+    from multimodal_transformer_amd import graphs
+    lin = torch.nn.Linear(32, 32).to(dev)
+    x = torch.randn(4, 32, device=dev)
+
+    def step():
+        lin.weight.grad = None
+        lin.bias.grad = None
+        y = lin(x).sum()
+        y.backward()
+        return y
+
+    keep = step()                                      # eager, default stream: `keep` holds the graph and its AccumulateGrad nodes
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with torch.cuda.stream(side):
+            step()                                     # (1) the once-only warning is spent here (or was, by an earlier test)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for _ in range(2):                                 # (2), (3)
+        with pytest.raises(graphs.StaleAutogradGraphError):
+            graphs.capture_step(step, warmup=1)
+    del keep                                           # (4)
+    torch.cuda.synchronize()
+    g, y_static = graphs.capture_step(lambda: step().detach(), warmup=1)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(y_static).all()
 
 
 def test_train_mode_capture_with_an_unindexed_device(dev):

@@ -68,13 +68,17 @@ def test_lstm_scan(dev, T, B, H, init):
     F.check_device_errors()                 # the four-CU scans' exchange time-out word must be zero
 
 
-def _oracle_mem_scan(apre, chat, Wm, W2, b2):
+def _oracle_mem_scan(apre, chat, Wm, W2, b2, drop=None):
+    """the memory recurrence of transformer/MFT/multiTransformer.py:221-224 behind the batched `attended` part of both gamma fc1 layers;
+    `drop` (T,B,128): the gamma{1,2}_dropout multipliers on relu(fc1) (:222-223), gamma1's 64 units first"""
     T, B, U = apre.shape
     MD, HG = chat.shape[-1], W2.shape[-1]
     mem = torch.zeros(B, MD, dtype=apre.dtype)
     out = []
     for t in range(T):
         u = torch.relu(apre[t] + mem @ Wm.t())
+        if drop is not None:
+            u = u * drop[t]
         g1 = torch.sigmoid(u[:, :HG] @ W2[0].t() + b2[0])
         g2 = torch.sigmoid(u[:, HG:] @ W2[1].t() + b2[1])
         mem = g1 * mem + g2 * chat[t]
@@ -100,6 +104,77 @@ def test_mfn_mem_scan(dev, T, B):
     assert _report(tag + " mem", out.detach().cpu(), ref.detach()) < OUT_RTOL
     for name, a, b in zip(("dapre", "dchat", "dWm", "dW2", "db2"), gl, leaves):
         assert _report(tag + " " + name, a.grad.cpu(), b.grad) < RELU_GRAD_RTOL, name
+
+
+@pytest.mark.parametrize("T,B", [(20, 3), (300, 33), (6, 300), (5, 1030)])
+def test_mfn_mem_scan_train_mode_mask_replay(dev, T, B):
+    """gamma{1,2}_dropout = Dropout(0.2) inside the memory scan (transformer/MFT/multiTransformer.py:168,172,222-223): the mask the
+    forward kernel draws (stream 1000, index = (t B + b) 128 + unit) is rebuilt with mmt_debug_dropout_mask and replayed through the
+    oracle — the memory trajectory AND every gradient, so a backward that regenerated or applied another mask than the forward would
+    fail here.  B = 3 / 33: one sequence per workgroup; 300: two; 1030: the general kernel."""
+    F = mta().functional
+    p, seed = 0.2, 4242 + T
+    tag = "memdrop%d_%d" % (T, B)
+    apre = R.gen_normal(tag + "a", (T, B, 128), 19)
+    chat = torch.tanh(R.gen_normal(tag + "c", (T, B, 128), 19))
+    Wm = R.gen_normal(tag + "wm", (128, 128), 19) / np.sqrt(128)
+    W2 = R.gen_normal(tag + "w2", (2, 128, 64), 19) / 8
+    b2 = 0.1 * R.gen_normal(tag + "b2", (2, 128), 19)
+    g = R.gen_normal(tag + "g", (T, B, 128), 19)
+    gl = [t.to(dev).requires_grad_() for t in (apre, chat, Wm, W2, b2)]
+    out = F.mfn_mem_scan(*gl, dropout_p=p, seed=seed)
+    (out * g.to(dev)).sum().backward()
+    keep, sc = F.dropout_mask(p, seed, 1000, T * B * 128, dev)
+    assert abs(float(1 - keep.float().mean()) - p) < 4 * np.sqrt(p * (1 - p) / keep.numel()) + 1e-3
+    drop = (keep.reshape(T, B, 128).double() * sc).cpu()
+    leaves = [t.double().requires_grad_() for t in (apre, chat, Wm, W2, b2)]
+    ref = _oracle_mem_scan(*leaves, drop=drop)
+    (ref * g.double()).sum().backward()
+    plain = _oracle_mem_scan(*[t.double() for t in (apre, chat, Wm, W2, b2)])
+    assert rel_l2(plain.numpy(), ref.detach().numpy()) > 1e-2, "the mask changed nothing: the test would not see a wrong one"
+    assert _report(tag + " mem", out.detach().cpu(), ref.detach()) < OUT_RTOL
+    for name, a, b in zip(("dapre", "dchat", "dWm", "dW2", "db2"), gl, leaves):
+        assert _report(tag + " " + name, a.grad.cpu(), b.grad) < RELU_GRAD_RTOL, name
+    out2 = F.mfn_mem_scan(*[t.detach() for t in gl], dropout_p=p, seed=seed)
+    assert torch.equal(out2, out.detach()), "same seed, same mask"
+
+
+@pytest.mark.parametrize("T,B", [(20, 3), (300, 33)])
+def test_mfn_gate_train_mode_mask_replay(dev, T, B, monkeypatch):
+    """The whole MFN module in TRAIN mode (gamma dropouts 0.2 inside the scan, out_dropout 0.5 behind the read-out's ReLU,
+    transformer/MFT/multiTransformer.py:168-176,222-223,245) against the oracle run with the masks the kernels drew: output, input
+    gradients of every modality and every parameter gradient at the eval-mode tolerances."""
+    MT, F, L = mta().multiTransformer, mta().functional, mta()._lib
+    mods = R.MODS_AVL
+    mfn = MT.MFN(mods, {m: 256 for m in mods}, 1, device=dev)
+    p32 = _load_into(mfn, seed=31)
+    mfn = mfn.to(dev).train()
+    seeds = {2: 777001 + T, 4: 777002 + T}
+    real = L.next_dropout_seed
+    monkeypatch.setattr(L, "next_dropout_seed", lambda device, site, holder=None, index=0: seeds[site] if site in seeds else real(device, site, holder, index))
+    x = {m: R.gen_normal("mfndrop:" + m, (T, B, 256), 31) for m in mods}
+    g = R.gen_normal("mfndrop:g", (B, T, 1), 31)
+    ins = {m: x[m].to(dev).requires_grad_() for m in mods}
+    y = mfn(ins)
+    (y * g.to(dev)).sum().backward()
+    pg, po = mfn.gamma1_dropout.p, mfn.out_dropout.p
+    assert pg == 0.2 and po == 0.5                      # the reference's constants (:168,172,176)
+    kg, sg = F.dropout_mask(pg, seeds[2], 1000, T * B * 128, dev)
+    ko, so = F.dropout_mask(po, seeds[4], 2001, T * B * 64, dev)       # linear out-dropout: index m * NP + n, NP = 64
+    gd = (kg.reshape(T, B, 128).double() * sg).cpu()
+    od = (ko.reshape(T, B, 64).double() * so).cpu()
+    pd = {k: v.double().requires_grad_() for k, v in p32.items()}
+    xd = {m: x[m].double().requires_grad_() for m in mods}
+    ref = oracle.mfn_gate(pd, "", xd, mods, gamma_drop=(gd[..., :64], gd[..., 64:]), out_drop=od)
+    (ref * g.double()).sum().backward()
+    tag = "mfn train %dx%d" % (T, B)
+    assert _report(tag + " out", y.detach().cpu(), ref.detach()) < OUT_RTOL
+    for m in mods:
+        assert _report(tag + " dx:" + m, ins[m].grad.cpu(), xd[m].grad) < RELU_GRAD_RTOL
+    scale = max(float(v.grad.abs().max()) for v in pd.values())
+    for n, q in mfn.named_parameters():
+        got, want = q.grad.cpu().numpy(), pd[n].grad.numpy()
+        assert grad_close(got, want, RELU_GRAD_RTOL, 3e-3 * scale), "%s: rel-L2 %.3e" % (n, rel_l2(got, want))
 
 
 def _load_into(module, seed=R.SEED):
@@ -200,6 +275,20 @@ def test_multi_transformer_golden(dev):
     lengths = list(fx["lengths"])
     ins = {m: R.gen_normal("model_mft:" + m, (4, 50, R.EMBED_AVL[m]), R.SEED).to(dev) for m in mods}
     _check_model(dev, fx, model, lambda mask: model(ins, mask, lengths), "model_mft_avl", lengths, 50)
+
+
+@pytest.mark.parametrize("name,mods,embed", R.MFT_SWEEP)
+def test_multi_transformer_sweep_shapes_golden(dev, name, mods, embed):
+    """the other models of the reference's MFT sweep (transformer/MFT/train.py:538-552): two-modality gates (VA, AL) and the 44-wide
+    acoustic embed run through other concatenation tables and row-GEMM paddings than VAL-88"""
+    fx = load_golden(name)
+    MT = mta().multiTransformer
+    model = MT.MultiTransformer(mods, embed, device=dev)
+    _load_into(model)
+    model = model.to(dev).eval()
+    lengths = list(fx["lengths"])
+    ins = {m: R.gen_normal(name + ":" + m, (4, 50, embed[m]), R.SEED).to(dev) for m in mods}
+    _check_model(dev, fx, model, lambda mask: model(ins, mask, lengths), name, lengths, 50)
 
 
 def test_mse_sum_loss_and_gradient(dev):

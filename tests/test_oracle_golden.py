@@ -162,9 +162,10 @@ def _model_shapes(kind, **kw):
         linear("out.0", 128, 256)
         linear("out.2", 1, 128)
     elif kind == "mft":
-        mods = R.MODS_AVL
+        mods = kw.get("mods") or R.MODS_AVL
+        embed = kw.get("embed") or R.EMBED_AVL
         for m in mods:
-            linear("embed_" + m, 256, R.EMBED_AVL[m])
+            linear("embed_" + m, 256, embed[m])
             for j in range(4):
                 linear("attn%s.linears.%d" % (m, j), 256, 256)      # dead parameters
             linear("ff%s.w_1" % m, 128, 256)
@@ -239,6 +240,17 @@ def test_multi_transformer():
     ins = {m: R.gen_normal("model_mft:" + m, (4, 50, R.EMBED_AVL[m]), R.SEED) for m in mods}
     out = oracle.multi_transformer(p, ins, R.prefix_mask(lengths, 50), mods, 8)
     _check_model(fx, p, out, "model_mft_avl", lengths, 50)
+
+
+@pytest.mark.parametrize("name,mods,embed", R.MFT_SWEEP)
+def test_multi_transformer_sweep_shapes(name, mods, embed):
+    """the other models of the reference's MFT sweep (transformer/MFT/train.py:538-552): VA-88, AL-88, VAL-44"""
+    fx = load_golden(name)
+    p = _params(_model_shapes("mft", mods=mods, embed=embed), fx)
+    lengths = list(fx["lengths"])
+    ins = {m: R.gen_normal(name + ":" + m, (4, 50, embed[m]), R.SEED) for m in mods}
+    out = oracle.multi_transformer(p, ins, R.prefix_mask(lengths, 50), mods, 8)
+    _check_model(fx, p, out, name, lengths, 50)
 
 
 def test_eval_ccc():

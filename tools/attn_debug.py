@@ -1,7 +1,7 @@
-"""Developer helper (GPU): attention core against the oracle at a few odd shapes (a checker script, hence under tests/)."""
+"""Developer helper (GPU): attention core against the oracle at a few odd shapes (a checker script: it imports the oracle, so it is not product code)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
 import torch, numpy as np
 import oracle
 from multimodal_transformer_amd import functional as F

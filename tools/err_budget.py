@@ -1,6 +1,6 @@
 """Developer helper (not a test): where does the SFT model's valence error come from?  Runs the HIP model on the GPU,
 then replays each downstream stage with the CPU oracle FROM THE GPU's intermediate, so each stage's own error shows.
-    python tests/err_budget.py [T] [B]
+    python tools/err_budget.py [T] [B]
 """
 import sys
 
@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
-sys.path.insert(0, __file__.rsplit("/", 1)[0] + "/golden")
+sys.path.insert(0, __file__.rsplit("/", 2)[0] + "/tests/golden")
 import oracle                                    # noqa: E402
 import recipe as R                               # noqa: E402
 from multimodal_transformer_amd import multiTransformer as MT, eval_ccc, functional as F   # noqa: E402

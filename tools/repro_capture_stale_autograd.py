@@ -4,7 +4,8 @@
 A training step is captured while the autograd graph of an earlier EAGER step is still referenced.  No kernel of this repository is
 involved in case `plain`: the model is a torch.nn.Linear.
 
-  python tools/repro_capture_stale_autograd.py            # runs the three cases below, each in a child process, and reports
+  python tools/repro_capture_stale_autograd.py            # runs cases `clean` and `guarded`, each in a child process, and reports
+  python tools/repro_capture_stale_autograd.py --with-plain   # MANUAL USE ONLY: also the case that crashes while holding the GPU
   case plain   : torch only, stale reference kept, torch.cuda.graph() directly        -> expected: the child dies (SIGSEGV) in capture_end
   case guarded : same, through multimodal_transformer_amd.graphs.capture_step          -> expected: StaleAutogradGraphError, exit code 0
   case clean   : no stale reference, through capture_step                              -> expected: captured and replayed, exit code 0
@@ -61,7 +62,8 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
         print("captured and replayed", flush=True)
         sys.exit(0 if case == "clean" else 4)
 else:
-    for case in ("clean", "guarded", "plain"):
+    cases = ("clean", "guarded") + (("plain",) if "--with-plain" in sys.argv else ())
+    for case in cases:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", case], capture_output=True, text=True, timeout=300)
         tail = (r.stdout.strip().splitlines() or [""])[-1]
         err = [l for l in r.stderr.splitlines() if "Fatal" in l or "Segmentation" in l or "Error" in l][:2]
