@@ -66,7 +66,7 @@ def site_flops_per_launch(site, M, T, d, f, n_layers=1):
         "chain:bwd_qkv+ln1>bwd_ffn2(below)>bwd_ffn1+ln2>bwd_outproj->dO": 6 * d * d + 4 * d * f + 2 * d * d,
         "attn_bwd_dkv_kernel": 6 * T * d,                               # dV, dP, dK  (S recomputed: no credit)
         "attn_bwd_dq_kernel": 2 * T * d,                                # dQ          (S, dP recomputed: no credit)
-        "attn_bwd_diag16_kernel": 8 * T * d,                            # dV, dP, dK, dQ in one launch (S recomputed: no credit)
+        "attn_bwd_pair16_kernel": 8 * T * d,                            # dV, dP, dK, dQ in one launch (S recomputed: no credit)
         "rowgemm<LNBWD>:bwd_qkv+ln1": 6 * d * d,
         "wgrad_kernel": (8 * d * d + 4 * d * f) * n_layers,             # one launch covers every layer
         "rowgemm<PLAIN>:outproj+res": 2 * d * d,
@@ -81,7 +81,7 @@ def site_flops_per_launch(site, M, T, d, f, n_layers=1):
 
 SITE_KERNELS = {          # launch site -> kernel symbol prefix in the rocprofv3 tables
     "attn_fwd_kernel": "attn_fwd_kernel", "attn_bwd_dkv_kernel": "attn_bwd_dkv_kernel", "attn_bwd_dq_kernel": "attn_bwd_dq_kernel",
-    "attn_bwd_diag16_kernel": "attn_bwd_diag16_kernel",
+    "attn_bwd_pair16_kernel": "attn_bwd_pair16_kernel",
     "chain:outproj+res>ln2+ffn1>ffn2+res": "encoder_post_attn_fwd_kernel",
     "chain:outproj+res>ln2+ffn1>ffn2+res>ln1+qkv(next)": "encoder_post_attn_fwd4_kernel",
     "chain:bwd_ffn2>bwd_ffn1+ln2>bwd_outproj->dO": "encoder_pre_attn_bwd_kernel",

@@ -1,57 +1,92 @@
 #!/usr/bin/env python3
-"""Developer tool: where does attn_bwd_diag16_kernel<train> spend its tile time?  Needs tools/bin/libmmt_abl.so (built with
--DMMT_ABLATIONS); runs the configs[3] encoder forward+backward with the stamped variant of the kernel (MMT_ABL=7)."""
+"""Developer tool: where does attn_bwd_pair16_kernel<train> spend its time?  Needs tools/bin/libmmt_abl.so (tools/build_diag.sh); runs the
+configs[3] attention core forward+backward with the stamped twin of the kernel (MMT_ABL=7), after checking that the twin's results are
+bit-identical to the product kernel's.  Slots: see the first line of tools/bin/gen/attn_bwd_pair_diag.h."""
 import ctypes
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["MMT_ABL"] = "7"
-os.environ["MMT_LIB_PATH"] = os.path.join(ROOT, "tools", "bin", "libmmt_abl.so")
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from multimodal_transformer_amd import multiTransformer as MT, _lib
 
-SEG = ["loop top", "exp + dropout + dS", "packs + dV/dK MFMAs + patch writes", "patch reads + dQ MFMA",
-       "next tile: row constants, operand reads, score MFMAs", "barrier", "dQ accumulation (LDS read-add-write)"]
-dev = torch.device("cuda:0")
-torch.manual_seed(0)
-B, T, d, h = 32, 500, 128, 8
-enc = MT.Encoder(MT.EncoderLayer(d, MT.MultiHeadedAttention(h, d), MT.PositionwiseFeedForward(d, 128, 0.1), 0.1), 6).to(dev).train()
-x = torch.randn(B, T, d, device=dev, requires_grad=True)
-mask = torch.ones(B, T, 1, device=dev)
-raw = ctypes.CDLL(_lib.LIB_PATH)
-raw.mmt_debug_set_attn_stamp_buffer.argtypes = [ctypes.c_void_p]
-stamps = torch.zeros(B * h * 16 * 16, dtype=torch.int64, device=dev)
-for _ in range(5):
-    enc(x, mask).sum().backward()
+SLOTS = [l.split()[1] for l in open(os.path.join(ROOT, "tools", "bin", "gen", "attn_bwd_pair_diag.h")).readline().split("Marker slots:")[1].split(",")]
+what = {"staged": "prologue: loads, staging, K^T fragments, first barrier", "sweep": "first score products (+ the late waves' first fence)",
+        "x": "X: exponentials, mask, dS, packs", "fence_x": "wait at the barrier behind X", "y": "Y: products, patch, dQ, next scores",
+        "fence_y": "wait at the barrier behind Y", "swept": "the early waves' last fence", "dkv_stored": "dK / dV stores issued",
+        "all_swept": "final barrier", "exit": "dQ read-out + stores, all stores retired"}
+
+
+def run(lib, stamped, B, T, d, h, p):
+    """one process per library: returns (dq, dk, dv[, stamps, us per launch])"""
+    import subprocess
+    code = r'''
+import ctypes, os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from multimodal_transformer_amd import functional as F, _lib
+dev = torch.device("cuda:0"); torch.manual_seed(0)
+B, T, d, h, p = %d, %d, %d, %d, %f
+q, k, v = (torch.randn(B, T, d, device=dev, requires_grad=True) for _ in range(3))
+g = torch.randn(B, T, d, device=dev); mask = torch.ones(B, T, 1, device=dev)
+for _ in range(5): F.sdpa(q, k, v, mask, h, p, 7).backward(g)
 torch.cuda.synchronize()
-assert raw.mmt_debug_set_attn_stamp_buffer(ctypes.c_void_p(stamps.data_ptr())) == 0
+stamps = None
+if %d:
+    raw = ctypes.CDLL(_lib.LIB_PATH); raw.mmt_debug_set_attn_stamp_buffer.argtypes = [ctypes.c_void_p]
+    stamps = torch.zeros(B * h * 8 * 32, dtype=torch.int64, device=dev)
+    assert raw.mmt_debug_set_attn_stamp_buffer(ctypes.c_void_p(stamps.data_ptr())) == 0
+q.grad = k.grad = v.grad = None
 _lib.profile(True)
-for _ in range(5):
-    enc(x, mask).sum().backward()
+for _ in range(20):
+    q.grad = k.grad = v.grad = None
+    F.sdpa(q, k, v, mask, h, p, 7).backward(g)
 torch.cuda.synchronize()
-ms, n = _lib.profile_collect()["attn_bwd_diag16_kernel"]
-print("attn_bwd_diag16 (stamped) %.2f us/launch" % (1e3 * ms / n))
-full = stamps.cpu().numpy().reshape(-1, 16).astype(float)
-live = full[full[:, 9] == 1]
-life = live[:, 7]
-print("live waves %d: lifetime median %.0f cycles (min %.0f max %.0f) = %.0f per tile" % (len(live), np.median(life), life.min(), life.max(), np.median(life) / 16))
-tot = live[:, :7].sum()
-for i, nm in enumerate(SEG):
-    print("  %-56s %6.0f cycles/tile  %5.1f %%" % (nm, live[:, i].mean() / 16, 100 * live[:, i].sum() / tot))
-# prologue (kernel entry -> first step), sweep, epilogue (last step -> stores retired) per workgroup; s_memtime bases differ between XCDs,
-# so only differences inside one workgroup are formed
-wg = full.reshape(B * h, 16, 16)
-pro = wg[:, :, 10].max(axis=1); swp = wg[:, :, 7].max(axis=1); epi = (wg[:, :, 15] - wg[:, :, 14]).max(axis=1)
-print("per workgroup, cycles: prologue median %.0f (max %.0f) | sweep median %.0f (min %.0f max %.0f) | epilogue median %.0f (max %.0f) | sum %.0f"
-      % (np.median(pro), pro.max(), np.median(swp), swp.min(), swp.max(), np.median(epi), epi.max(), np.median(pro + swp + epi)))
-# in-kernel clock: s_memtime ticks (shader clock) over s_memrealtime ticks (constant 100 MHz) around the same body, kernel entry -> stores retired
-ck, rt = live[:, 11], live[:, 12]
-ok = rt > 0
-ghz = ck[ok] / rt[ok] * 0.1
-print("in-kernel clock (s_memtime / s_memrealtime x 100 MHz), live waves: median %.3f GHz (5%% %.3f, 95%% %.3f); kernel entry -> exit median %.0f cycles = %.2f us"
-      % (np.median(ghz), np.percentile(ghz, 5), np.percentile(ghz, 95), np.median(ck[ok]), np.median(rt[ok]) / 100.0))
-span = (full[:, 8].max() - full[full[:, 13] > 0][:, 13].min()) / 100.0
-print("first workgroup entry -> last exit of the LAST stamped launch (100 MHz clock, chip-wide): %.2f us" % span)
+prof = _lib.profile_collect()
+name = [n for n in prof if n.startswith("attn_bwd")][0]
+np.savez(sys.argv[1], dq=q.grad.cpu().numpy(), dk=k.grad.cpu().numpy(), dv=v.grad.cpu().numpy(), us=1e3 * prof[name][0] / prof[name][1],
+         stamps=(stamps.cpu().numpy() if stamps is not None else np.zeros(1)))
+''' % (ROOT, B, T, d, h, p, 1 if stamped else 0)
+    out = "/tmp/stamps_%d.npz" % (1 if stamped else 0)
+    env = dict(os.environ)
+    if lib:
+        env["MMT_LIB_PATH"] = lib
+    if stamped:
+        env["MMT_ABL"] = "7"
+    else:
+        env.pop("MMT_ABL", None)
+    subprocess.run([sys.executable, "-c", code, out], check=True, env=env)
+    return np.load(out)
+
+
+B, T, d, h, p = 32, 500, 128, 8, 0.1
+if len(sys.argv) > 1:
+    B, T, d, h = (int(a) for a in sys.argv[1:5])
+abl = os.path.join(ROOT, "tools", "bin", "libmmt_abl.so")
+ref = run(None, False, B, T, d, h, p)
+st = run(abl, True, B, T, d, h, p)
+for n in ("dq", "dk", "dv"):
+    assert np.array_equal(ref[n], st[n]), "stamped twin differs from the product kernel in " + n
+print("stamped twin == product kernel, bit for bit (dQ, dK, dV); product %.2f us/launch, stamped %.2f us/launch" % (float(ref["us"]), float(st["us"])))
+full = st["stamps"].reshape(-1, 32).astype(float)
+full = full[full[:, 31] == 1]
+nw = len(full)
+life = full[:, 28]
+ghz = life / (full[:, 30] - full[:, 29]) * 0.1
+print("waves %d; entry -> exit median %.0f cycles (min %.0f, max %.0f) at %.2f GHz = %.2f us" % (nw, np.median(life), life.min(), life.max(), np.median(ghz), np.median(life) / np.median(ghz) / 1e3))
+span = (full[:, 30].max() - full[:, 29].min()) / 100.0
+print("first entry -> last exit chip-wide (100 MHz clock): %.2f us" % span)
+wg = full.reshape(-1, 8, 32) if nw % 8 == 0 else None
+if wg is not None:
+    simd = (wg[:, :, 27].astype(np.int64) >> 4) & 3
+    pats = {}
+    for row in simd:
+        pats[tuple(row)] = pats.get(tuple(row), 0) + 1
+    print("SIMD of waves 0..7 of a workgroup (HW_ID), by frequency:", sorted(pats.items(), key=lambda kv: -kv[1])[:6])
+for grp, rows in (("early waves 0-3", [0, 1, 2, 3]), ("late waves 4-7", [4, 5, 6, 7])):
+    if wg is None:
+        break
+    sub = wg[:, rows, :].reshape(-1, 32)
+    print("  %s:" % grp)
+    for i, n in enumerate(SLOTS[1:], start=1):
+        print("    %-12s %8.0f cycles  %5.1f %%   %s" % (n, sub[:, i].mean(), 100 * sub[:, i].mean() / sub[:, 28].mean(), what.get(n, "")))
