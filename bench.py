@@ -104,15 +104,24 @@ def kernel_source_sha():
     return hsh.hexdigest()[:16]
 
 
-def pmc_traffic(site, train, cfg):
-    """HBM-side bytes per launch of the site's kernel from a committed rocprofv3 counter summary (separate --pmc passes of
-    this same workload; FETCH_SIZE x2 + WRITE_SIZE, KiB units — MI355X_MICROARCH.md 'HBM').  bench.py cannot run the
-    profiler around itself, so the figure is read from profiles/ — and ONLY from a summary collected on exactly the kernel
-    sources that are running now (`_meta.csrc_sha`), for this workload and mode; otherwise traffic is null and the reason is
-    given instead of a stale number."""
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+# Vector-issue ceilings of the attention kernels at d_k = 16: cycles of SIMD issue per 32x32 score tile from the kernel's
+# per-score instruction list and the per-instruction costs measured by tools/valu_micro.hip (profiles/r05_valu_micro.txt: v_exp_f32 8.2,
+# v_bfe_i32 / v_cvt_pk_bf16_f32 / v_max3_f32 4.2, v_and / v_mul / v_add 2.3, v_fma 2.4 per wave64 instruction and SIMD with >= 2 waves
+# resident; an MFMA holds the SIMD's issue for 8), against the matrix pipe's 1017 FLOP per cycle and SIMD (2.5 PFLOP/s / 1024 SIMDs / 2.4 GHz).
+# value = (credited FLOP per tile / issue cycles per tile) / 1017 = the fraction of the bf16 MFMA peak at which vector issue saturates.
+VALU_CEILING = {
+    # per register (16 per tile): exp, bfe, and, mul, fma, cvt = 8.2 + 4.2 + 2.3 + 2.3 + 2.4 + 4.2; 8 MFMAs; 8 * 32 * 32 * 16 FLOP credited
+    "attn_bwd_pair16_kernel": (8 * 32 * 32 * 16) / (16 * (8.2 + 4.2 + 2.3 + 2.3 + 2.4 + 4.2) + 8 * 8) / 1017.0,
+    # per register: exp, bfe, and, add (row sum), half a max3, half a cvt; 3 MFMAs; 4 * 32 * 32 * 16 FLOP credited
+    "attn_fwd_kernel": (4 * 32 * 32 * 16) / (16 * (8.2 + 4.2 + 2.3 + 2.3 + 2.1 + 2.1) + 3 * 8) / 1017.0,
+}
+
+
+def pmc_table(train, cfg):
+    """the newest counter table under profiles/ collected for this workload and mode on the running kernel sources -> (table, path) or (None, why)"""
     import glob
-    if site not in SITE_KERNELS:
-        return None, "no counter mapping for this launch site"
     sha, why = kernel_source_sha(), "no counter table of this workload and mode under profiles/"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_kernel*.json")), reverse=True):
         try:
@@ -122,17 +131,49 @@ def pmc_traffic(site, train, cfg):
             continue
         meta, rel = tab.get("_meta", {}), os.path.relpath(path, ROOT)
         if meta.get("workload") != cfg["desc"] or bool(meta.get("train")) != bool(train):
-            continue                                    # another workload's / mode's table
+            continue
         if meta.get("csrc_sha") != sha:
-            if not why.startswith("stale"):             # name the NEWEST table of this workload, not the oldest
+            if not why.startswith("stale"):
                 why = "stale: %s was collected on kernel sources %s, running %s" % (rel, meta.get("csrc_sha"), sha)
             continue
-        pref = SITE_KERNELS[site]
-        for k, v in tab.items():
-            if k.startswith(pref) and "hbm_bytes_per_launch" in v:
-                return int(v["hbm_bytes_per_launch"]), "%s (%s)" % (rel, k)
-        why = "%s has no entry for %s" % (rel, pref)
+        return tab, rel
     return None, why
+
+
+def step_hbm(train, cfg, ms_per_step):
+    """HBM-side bytes of one whole step (every kernel of this library in the counter table x its launches per profiled step) and the
+    average rate they amount to over the measured step time -> dict, or None with the reason"""
+    tab, src = pmc_table(train, cfg)
+    if tab is None:
+        return {"hbm_bytes_per_step": None, "source": src}
+    if "steps_profiled" not in tab["_meta"]:
+        return {"hbm_bytes_per_step": None, "source": src + ": collected without --headline-only (its dispatch counts mix other shapes)"}
+    steps = float(tab["_meta"]["steps_profiled"])
+    tot = 0.0
+    for k, v in tab.items():
+        if k == "_meta" or k.startswith("at::") or k.startswith("__amd") or "hbm_bytes_per_launch" not in v:
+            continue
+        tot += v["hbm_bytes_per_launch"] * v.get("dispatches", 0) / steps
+    gbps = tot / (ms_per_step * 1e-3) / 1e9
+    return {"hbm_bytes_per_step": int(tot), "hbm_gbps": round(gbps, 1), "hbm_frac": round(gbps / HBM_PEAK_GBPS, 4), "source": src}
+
+
+def pmc_traffic(site, train, cfg):
+    """HBM-side bytes per launch of the site's kernel from a committed rocprofv3 counter summary (separate --pmc passes of
+    this same workload; FETCH_SIZE x2 + WRITE_SIZE, KiB units — MI355X_MICROARCH.md 'HBM').  bench.py cannot run the
+    profiler around itself, so the figure is read from profiles/ — and ONLY from a summary collected on exactly the kernel
+    sources that are running now (`_meta.csrc_sha`), for this workload and mode; otherwise traffic is null and the reason is
+    given instead of a stale number."""
+    if site not in SITE_KERNELS:
+        return None, "no counter mapping for this launch site"
+    tab, src = pmc_table(train, cfg)
+    if tab is None:
+        return None, src
+    pref = SITE_KERNELS[site]
+    for k, v in tab.items():
+        if k.startswith(pref) and "hbm_bytes_per_launch" in v:
+            return int(v["hbm_bytes_per_launch"]), "%s (%s)" % (src, k)
+    return None, "%s has no entry for %s" % (src, pref)
 
 
 def roofline_of(prof, nsteps, M, T, d, f, N, train, cfg, top=12):
@@ -148,6 +189,13 @@ def roofline_of(prof, nsteps, M, T, d, f, N, train, cfg, top=12):
             "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": cnt // nsteps, "flops_per_launch": fl,
             "share_of_kernel_time": round(tot_ms / sum(v[0] for v in prof.values()), 3)}
+    # the same kernel against the chip's HBM peak (north_star: "rocprof HBM GB/s ... reported against chip peak")
+    roof["hbm_gbps"] = round(traffic / avg_s / 1e9, 1) if traffic and avg_s > 0 else None
+    roof["hbm_frac"] = round(roof["hbm_gbps"] / HBM_PEAK_GBPS, 4) if roof["hbm_gbps"] is not None else None
+    # ... and against the ceiling its own vector instructions set (the softmax arithmetic issues on the SIMD the MFMAs issue on)
+    if name in VALU_CEILING:
+        roof["valu_ceiling_frac"] = round(VALU_CEILING[name], 4)
+        roof["frac_of_valu_ceiling"] = round(roof["frac"] / VALU_CEILING[name], 3)
     return kernel_ms, roof
 
 
@@ -353,10 +401,14 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-model", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="only the headline step (profiling runs: every dispatch of a kernel is then one of "
+                    "the headline shape, so per-dispatch counter averages and dispatch counts belong to it alone)")
     ap.add_argument("--eval-mode", action="store_true", help="dropout as identity (parity-test arithmetic) instead of train mode")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU number of sequences (experiments only)")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra eager steps with per-kernel HIP-event timing")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_full_model = True
 
     # Under a launcher (torchrun sets RANK and LOCAL_RANK for every rank) the world size is the launcher's; a WORLD_SIZE that some
     # scheduler preset for a process that is nobody's rank means nothing.
@@ -404,7 +456,10 @@ def main():
     mask = torch.ones(B, T, 1, device=dev)                   # throughput runs use full-length sequences (§8d)
     nvalid = float(world * B * T)
 
+    calls = [0]                                             # every execution of the headline step in this process (eager or while capturing)
+
     def fwd_bwd():
+        calls[0] += 1
         for p in params:
             p.grad = None
         x.grad = None
@@ -419,7 +474,7 @@ def main():
     # ---- the same step followed by the reference's optimiser (Adam lr 1e-4, weight decay 1e-4: transformer/SFT/train.py:621);
     #      reported beside the headline, never as it ("with and without Adam + all-reduce")
     adam = None
-    if rank == 0 or world > 1:
+    if (rank == 0 or world > 1) and not args.headline_only:
         from multimodal_transformer_amd.optim import FlatAdam
         opt = FlatAdam(params, lr=1e-4, weight_decay=1e-4)       # torch.optim.Adam's update as one launch over the flat parameter buffer
         def step_adam():
@@ -441,7 +496,7 @@ def main():
     # ---- the same step as two half-batches on two HIP streams inside one graph (Encoder.sub_batch_streams = 2): reported beside the
     #      headline, never as it — the headline's kernels have the GPU to themselves, which is what the roofline line prices
     two_streams = None
-    if rank == 0 and world == 1 and B >= 2:
+    if rank == 0 and world == 1 and B >= 2 and not args.headline_only:
         enc.sub_batch_streams = 2
         try:
             trun = Runner(fwd_bwd, params, 1, not args.no_graph, 3)
@@ -668,6 +723,8 @@ def main():
             "algorithmic_mflop_per_window": round(fpw / 1e6, 3),
             "step_mfma_frac": round(value * fpw / (world * MFMA_BF16_PEAK_TFLOPS * 1e12), 5),
             "roofline": roofline,
+            "step_hbm": step_hbm(train, cfg, ms_per_step),
+            "fwd_bwd_calls": calls[0],
             "kernel_ms_per_step": kernel_ms,
         }
         if ar_ms is not None:

@@ -16,7 +16,7 @@ BENCH="$REPO/bench.py --workload $WL"
 # sizes and would blur the per-kernel averages the roofline line is checked against)
 echo "== kernel-trace + stats of: python3 bench.py --no-full-model --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python3 $BENCH --no-full-model --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.log || exit 1
-SHORT="--steps 3 --warmup 1 --profile-steps 0 --no-graph --no-full-model --no-cpu-baseline"
+SHORT="--steps 3 --warmup 1 --profile-steps 0 --no-graph --headline-only --no-cpu-baseline"
 # (the last three groups answer "how much does a kernel pull from L2 into the CUs" and "how scalar is it"; a counter name this rocprofv3
 # does not know fails its own pass only)
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do

@@ -54,12 +54,13 @@ for f in glob.glob(os.path.join(out, "pmc_FETCH_SIZE.json")):
     try:
         line = [l for l in open(f) if l.startswith("{")][-1]
         cfg = json.loads(line)["config"]
+        ncalls = json.loads(line).get("fwd_bwd_calls")         # eager executions of the headline step in a counter pass (--headline-only --no-graph)
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench
         res["_meta"] = {"workload": cfg["workload"].split("; fwd")[0], "train": cfg["dropout"].startswith("train"),
-                        "csrc_sha": bench.kernel_source_sha(),
+                        "csrc_sha": bench.kernel_source_sha(), "steps_profiled": ncalls,
                         "command": "rocprofv3 --kernel-trace --pmc <one counter group per run> -- python3 bench.py --steps 3 --warmup 1 "
-                                   "--profile-steps 0 --no-graph --no-full-model --no-cpu-baseline",
+                                   "--profile-steps 0 --no-graph --headline-only --no-cpu-baseline",
                         "units": "averages per dispatch; FETCH_SIZE/WRITE_SIZE in KiB as reported; hbm_* bytes = 2*1024*FETCH_SIZE + "
                                  "1024*WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md 'HBM'); SQ_* cycle counters in quad-cycles "
                                  "except SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CYCLES"}
