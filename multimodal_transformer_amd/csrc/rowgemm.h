@@ -549,24 +549,25 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         float mean = 0.f, rstd = 0.f;
         if (m < M) { mean = p.st[2 * (size_t)m]; rstd = p.st[2 * (size_t)m + 1]; }
         if (WIDE && j == 0) { cr[NP] = mean; cr[NP + 1] = rstd; }        // pad columns of the tile row (ldf = NP + 4): for the column pass
-        if (!WIDE && NP <= 8 * TPR) {
-        // Row tile of at most two 4-column pieces per thread (d_model <= 128 with 16 threads per row): ONE pass over memory.  The first
+        constexpr int LNB_ITS = WIDE ? 4 : 2;         // 4-column pieces per thread that the one-pass form keeps in registers
+        if (NP <= 4 * TPR * LNB_ITS) {
+        // Row tile of at most two (d_model <= 128) or four (WIDE: <= 256; 16 threads per row) 4-column pieces per thread: ONE pass over memory.  The first
         // pass's operands — x-hat and dy a, and the residual gradient, fetched beside them — stay in registers across the two row
         // reductions, so the second pass reads nothing (round 4 read x, a and dy a second time: two dependent round trips to L2 per
         // stage, the largest phase of the backward chains: DESIGN.md 4.1b).  Same expressions in the same order: bit-identical results.
         float s1 = 0.f, s2 = 0.f;
-        f32x4 gk[2], xk[2], rk[2];
+        f32x4 gk[LNB_ITS], xk[LNB_ITS], rk[WIDE ? 1 : LNB_ITS];     // (WIDE fetches the residual gradient in the second pass: registers)
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
+        for (int it = 0; it < LNB_ITS; ++it) {
             const int c = j * 4 + it * 4 * TPR;
-            gk[it] = f32x4{0.f, 0.f, 0.f, 0.f}; xk[it] = gk[it]; rk[it] = gk[it];
+            gk[it] = f32x4{0.f, 0.f, 0.f, 0.f}; xk[it] = gk[it]; if (!WIDE) rk[it] = gk[it];
             if (c >= NP) continue;
             f32x4 g = {0.f, 0.f, 0.f, 0.f}, xh = {0.f, 0.f, 0.f, 0.f};
             if (m < M && c < d) {
                 f32x4 dy = *reinterpret_cast<const f32x4*>(cr + c);
                 f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + (size_t)m * p.ldx + c);
                 f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_a + c);
-                if (p.dres) rk[it] = *reinterpret_cast<const f32x4*>(p.dres + (size_t)m * p.lddres + c);
+                if (!WIDE && p.dres) rk[it] = *reinterpret_cast<const f32x4*>(p.dres + (size_t)m * p.lddres + c);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     xh[i] = (xv[i] - mean) * rstd;
@@ -574,14 +575,16 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                     s1 += g[i];
                     s2 += g[i] * xh[i];
                 }
-                f32x4 gx;
+                if (!WIDE) {
+                    f32x4 gx;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) gx[i] = dy[i] * xh[i];
-                *reinterpret_cast<f32x4*>(gr + c) = gx;
+                    for (int i = 0; i < 4; ++i) gx[i] = dy[i] * xh[i];
+                    *reinterpret_cast<f32x4*>(gr + c) = gx;
+                }
                 gk[it] = g; xk[it] = xh;
             } else {
                 *reinterpret_cast<f32x4*>(cr + c) = g;
-                *reinterpret_cast<f32x4*>(gr + c) = g;
+                if (!WIDE) *reinterpret_cast<f32x4*>(gr + c) = g;
             }
         }
         s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
@@ -593,14 +596,14 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             const float sigma = live ? 1.0f / rstd - p.eps : 1.f;
             const float k1 = s1 / (float)d, k2 = s2 / ((float)(d - 1) * sigma);
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
+            for (int it = 0; it < LNB_ITS; ++it) {
                 const int c = j * 4 + it * 4 * TPR;
                 if (c >= ((KEEP & KEEP_AS) ? NP : d)) continue;
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
                 if (live && c < d) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[i] = rstd * (gk[it][i] - k1) - k2 * xk[it][i];
-                    if (p.dres) o += rk[it];
+                    if (p.dres) { if (WIDE) o += *reinterpret_cast<const f32x4*>(p.dres + (size_t)m * p.lddres + c); else o += rk[it]; }
                     *reinterpret_cast<f32x4*>(p.out_f32 + (size_t)m * p.ldo + c) = o;
                     if (KEEP & KEEP_X) *reinterpret_cast<f32x4*>(Xs + row * sm.ldx + c) = o;
                 }
