@@ -69,6 +69,19 @@ def test_adam_steps_follow_the_oracle(dev):
     dist = rel_l2(torch.cat(ups).numpy(), torch.cat(ups_o).numpy())
     print("relative distance between the two accumulated updates: %.3e" % dist)
     assert dist < 0.18        # measured 0.138 (x1.3): Adam turns small gradient differences of small gradients into full-size steps
+    # ... and what north_star cares about: the two TRAINED models still give the same valence track.  A fresh batch through both: per
+    # sequence CCC >= 1 - 1e-3 and rel-L2 under the forward tolerance, although the parameters took sign-of-noise steps where their
+    # gradients are analytically zero.
+    from multimodal_transformer_amd import eval_ccc
+    xe = torch.tanh(R.gen_normal("adam:eval:x", (B, T, 512), 31))
+    with torch.no_grad():
+        ye = model(xe.to(dev), mask.to(dev), lengths).cpu().numpy()
+        yo = oracle.nlp_transformer({k: v.detach() for k, v in po.items()}, xe, mask, 4).numpy()
+    for b, L in enumerate(lengths):
+        r = rel_l2(ye[b, :L], yo[b, :L])
+        ccc = eval_ccc(yo[b, :L].reshape(-1), ye[b, :L].reshape(-1)) if L > 2 else 1.0
+        print("after %d Adam steps, sequence %d (len %d): valence rel_l2 %.3e  CCC %.6f" % (steps, b, L, r, ccc))
+        assert r < 2e-2 and ccc >= 1 - 1e-3
 
 
 def test_loss_decreases_in_train_mode(dev):
