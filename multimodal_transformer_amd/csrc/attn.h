@@ -114,18 +114,9 @@ __device__ __forceinline__ AttnBlock attn_block(int nx, int nbh) {
 }
 __host__ inline int attn_grid(int nx, int nbh) { return nx * 8 * ((nbh + 7) / 8); }
 
-// ABL != 0: timing-only ablations (results are WRONG; tools/attn_ablate.py): 1 no running max / rescale, 2 no exp,
-// 3 no PV product, 5 no row sums,
-// 6 correct results + s_memtime stamps at seven points of the tile body, summed per wave into g_attn_stamps (diagnostic build)
-#ifdef MMT_ABLATIONS
-__device__ unsigned long long* g_attn_stamps = nullptr;        // [wave id][16]: 0..5, 7 segment sums; 6 wave lifetime; 8 / 9 entry / exit (100 MHz)
-#define ATT_STAMP(n) do { if (ABL == 6) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
-    st_acc[n] += t_ - st_prev; st_prev = t_; } } while (0)
-#else
-#define ATT_STAMP(n)
-#endif
-template <int DKP, bool DROP, int ABL = 0>
+// (`//@ name` comment lines mark the phase boundaries at which tools/make_diag.py inserts cycle stamps into the GENERATED stamped twin of this
+// kernel — diagnostic builds only; this file holds no diagnostic code)
+template <int DKP, bool DROP>
 __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
         const bf16* __restrict__ Qr, const bf16* __restrict__ Kr, const bf16* __restrict__ Vr,
         bf16* __restrict__ ctx, float* __restrict__ lse,
@@ -133,10 +124,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
     constexpr int KS = DKP / 16;
     constexpr int DKB = DKP < 32 ? DKP : 32;           // feature rows of this launch's output block
     constexpr bool ONES = (DKP == 16) && !DROP;        // row sums through the MFMA
-#ifdef MMT_ABLATIONS
-    unsigned long long st_entry = 0, st_entry_rt = 0;
-    if (ABL == 6) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_entry), "=s"(st_entry_rt) :: "memory");
-#endif
+    //@ entry
     // 16-byte pieces per tile: K (R layout, all DKP features) and the 32-feature block `fb` of V — ALSO in the R layout, as the QKV
     // epilogue wrote it: the PV product contracts over keys, its A fragment (8 keys of one feature per lane) comes out of LDS
     // through transposing reads (tr_frag2), so no transposed copy of V exists in memory
@@ -195,14 +183,10 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
     // consumers of its result: hipcc's hazard recognizer counts a skippable block's instructions as MFMA->VALU wait
     // states, which is wrong on the taken path — seen as 27 % wrong dQ in attn_bwd_dq_kernel<32>), TAIL = true for the
     // last key tile, whose index masking is then straight-line code.
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
-    (void)st_acc; (void)st_prev;
-#ifdef MMT_ABLATIONS
-    if (ABL == 6) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev) :: "memory");
-#endif
+    //@ prologue
     auto body = [&](auto tail_tag, int kt) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        ATT_STAMP(7);                                   // loop overhead since the last barrier
+        //@ loop_top
         progress_prio(kt, nt);
         const uint32_t tw = mw;                          // this tile's keep bits
         if (DROP && !TAIL) mw = mrow[(size_t)(kt + 1) * 64];
@@ -230,15 +214,12 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
             for (int i = 0; i < 16; ++i) s[i] = (kt * 32 + acc32_row(i, hh) < T) ? s[i] : -INFINITY;
         }
         // (no inline asm here: hipcc's hazard recognizer does not count an asm statement as a reader of MFMA results)
-        float tmax = 0.f;
-        if (ABL != 1) {
-        tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
+        float tmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
         for (int i = 3; i < 15; i += 2) tmax = fmaxf(fmaxf(tmax, s[i]), s[i + 1]);
         tmax = fmaxf(tmax, s[15]);                      // over this lane's 16 keys; the other half of the wave holds the query's other 16
-        }
-        ATT_STAMP(0);                                   // K fragment read, QK^T, tile maximum
-        if (ABL != 1 && (kt == 0 || __any(tmax > MMT_RESCALE_THR))) {      // __any looks at both halves: no exchange on the common path
+        //@ qk_max
+        if (kt == 0 || __any(tmax > MMT_RESCALE_THR)) {      // __any looks at both halves: no exchange on the common path
             // move the reference to the new running max (first tile: from 0 to the tile max, with o = l = 0)
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));  // finite: every tile holds >= 1 real key in one of the halves
             const float dlt = (kt == 0) ? tmax : fmaxf(tmax, 0.f);
@@ -250,39 +231,33 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
             fill16(mneg, -mrun);
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = (ABL == 2) ? s[i] * 0.01f : fast_exp2(s[i]);
-        if (!ONES && ABL != 5) {        // row sum of the tile as ONE chain of plain adds: a wave issues a vector instruction every 6+ cycles
+        for (int i = 0; i < 16; ++i) s[i] = fast_exp2(s[i]);
+        if (!ONES) {        // row sum of the tile as ONE chain of plain adds: a wave issues a vector instruction every 6+ cycles
             float a = s[0];             // anyway, so the dependency costs nothing, and a v_add_f32 takes 1.6 cycles of SIMD issue where the
 #pragma unroll                          // v_pk_add_f32 that two parallel chains get packed into takes 3.7 (tools/valu_micro.hip)
             for (int i = 1; i < 16; ++i) a += s[i];
             lrun += a;
         }
-        ATT_STAMP(1);                                   // rescale decision, exponentials, row sums
+        //@ exp_sum
         if (DROP) {                                     // zero the dropped probabilities; 1/(1-p) is applied once, to the output row
             static_for<0, 16>([&](auto ic) { constexpr int i = decltype(ic)::value; s[i] = keep_and<i>(s[i], tw); });
         }
-        ATT_STAMP(2);                                   // mask wait + selects
+        //@ mask
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             bf16x8 va = tr_frag2(sv + 128 * s2, sv + 128 * s2 + 64);       // keys 16 s2 + 4 hh + {0..3}, then + 8
             if (ONES && r == DKP) va = ones;           // V^T rows >= DKP read zeros; row DKP becomes the ones row
-            if (ABL == 3) {
-                const bf16x8 pk = pack8(s, s2);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[8 * s2 + j] += (float)pk[j] + (float)va[j];
-            } else
             o = mfma32(va, pack8(s, s2), o);
         }
-        ATT_STAMP(3);                                   // V fragment reads, packs, PV issue
+        //@ pv
         if (!TAIL) stg.store(stage[(kt + 1) & 1]);
-        ATT_STAMP(4);                                   // wait for the staged tile's global loads + LDS writes
+        //@ stage_wait
         __syncthreads();        // stage[(kt+1)&1] was last read at tile kt-1, i.e. before the previous barrier
-        ATT_STAMP(5);                                   // barrier
+        //@ barrier
     };
     for (int kt = 0; kt < nt - 1; ++kt) body(std::false_type{}, kt);
     body(std::true_type{}, nt - 1);
-#ifdef MMT_ABLATIONS
-#endif
+    //@ swept
     if (!live) return;
     float ltot;
     if (ONES) ltot = __shfl(o[8], r);                  // O^T row 16 = (register 8, lower half): the row sums
@@ -302,19 +277,7 @@ __global__ __launch_bounds__(MMT_THREADS, 2) void attn_fwd_kernel(
             *reinterpret_cast<bf16x4*>(ctx + m * ldc + head * DKP + e0) = v;
         }
     }
-#ifdef MMT_ABLATIONS
-    if (ABL == 6 && g_attn_stamps) {
-        unsigned long long t1, r1;
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
-        if (lane == 0) {
-            unsigned long long* q = g_attn_stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
-            for (int i = 0; i < 8; ++i) q[i] = st_acc[i];
-            q[6] = t1 - st_entry; q[8] = st_entry_rt; q[9] = r1;
-            q[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
-            q[11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
-        }
-    }
-#endif
+    //@ exit
 }
 
 // ------------------------------------------------------------------------------------------------
