@@ -129,7 +129,12 @@ def test_module_train_mode_runs_and_reseeds(dev):
                                                 (2, 70, 256, 8, [70, 33], 0.1),          # d_k 32, two-kernel backward
                                                 (3, 33, 40, 4, [33, 20, 1], 0.25),       # d_k 10 (padded to 16), ragged tail tile
                                                 (1, 520, 128, 8, [520], 0.1),            # 17 key tiles: two-kernel backward at d_k 16
-                                                (2, 70, 256, 4, [70, 41], 0.1)])         # d_k 64: two feature blocks
+                                                (2, 70, 256, 4, [70, 41], 0.1),          # d_k 64: two feature blocks
+                                                # the one-kernel backward's corner cases in TRAIN mode (attn_bwd_pair.h): 9 key tiles (an odd count: the
+                                                # last wave owns one key tile, a blank query tile pads the sweep) with a one-key last tile; 15 tiles with a
+                                                # ragged tail; 16 full tiles; a padded head (d_k 10) at 10 tiles
+                                                (2, 257, 128, 8, [257, 130], 0.1), (1, 470, 64, 4, [470], 0.1), (1, 512, 128, 8, [512], 0.1),
+                                                (2, 300, 40, 4, [300, 41], 0.1)])
 def test_standalone_attention_train_mode_replay(dev, B, T, d, h, lengths, p):
     """attention() / MultiHeadedAttention outside the fused stack apply nn.Dropout to p_attn in train mode
     (transformer/MFT/multiTransformer.py:31-33): the stored bit masks (stream 0) are extracted and replayed through the oracle,
