@@ -139,7 +139,7 @@ def test_linear(dev, M, K, N, act, rs):
 @pytest.mark.parametrize("B,T,d,h,lengths", [
     (2, 50, 128, 8, [50, 20]), (3, 33, 40, 4, [33, 32, 1]), (2, 64, 256, 8, [64, 7]), (1, 1, 16, 1, [1]),
     (2, 300, 40, 4, [300, 41]), (1, 500, 128, 8, [350]), (1, 257, 256, 8, [257]),
-    # one-kernel backward (attn_bwd_fused.h: d_k <= 16, 9..16 key tiles): 9 tiles, a full last tile, 16 tiles with a ragged tail
+    # one-kernel backward (attn_bwd_pair.h: d_k <= 16, 9..16 key tiles): 9 tiles, a full last tile, 16 tiles with a ragged tail
     (2, 257, 128, 8, [257, 256]), (1, 512, 64, 4, [512]), (2, 481, 128, 8, [481, 3]),
     # d_k = 64 and d_k = 48 (padded to 64): two 32-feature output blocks per launch pair
     (2, 70, 256, 4, [70, 33]), (1, 33, 192, 4, [20]), (1, 300, 128, 2, [300])])
