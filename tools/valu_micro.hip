@@ -7,8 +7,8 @@
 // cycles per v_add_f32 against the 4 of MI355X_MICROARCH.md's constants table).  This form
 //   * records for EVERY wave where it ran (HW_REG_HW_ID: SE / SH / CU / SIMD, HW_REG_XCC_ID) and when (s_memrealtime at entry and exit,
 //     100 MHz, plus s_memtime for the clock), and derives the occupancy from that record: per SIMD the number of waves whose lifetimes
-//     overlap, and the rate over the OVERLAP WINDOW only (instructions retired inside the window by the waves resident in it, assuming
-//     each wave's own rate is constant over its life) — the "resident" columns;
+//     overlap at the SIMD's busiest moment ("res"), and the SIMD's throughput as ALL instructions its waves retired over the span from its
+//     first wave's entry to its last wave's exit ("/SIMD");
 //   * prints the wall-clock figure beside it (launch time by HIP events / instructions per SIMD): both must agree within 10 %;
 //   * places one workgroup of 4 w waves per CU for w <= 4 (one workgroup cannot be split over CUs, and its waves go round the four
 //     SIMDs), and TWO workgroups of 16 waves for w = 8, which the dispatcher may or may not co-schedule: the record tells;
@@ -199,18 +199,18 @@ static Row measure(Rec* dbuf, int cus, int w, int iters, double empty_cyc_per_it
             if (cur > best || (cur == best && ev[e + 1].first - ev[e].first > be - bs)) { best = cur; bs = ev[e].first; be = ev[e + 1].first; }
         }
         if (be <= bs) continue;
-        // instructions retired in [bs, be] by the waves alive throughout it, each at its own mean rate (the loop overhead is not
-        // subtracted here: it overlaps with the other waves' instructions; at 128 instructions per iteration it is a few per cent)
-        double instr = 0.0, cyc_per_tick = 0.0; int alive = 0;
-        for (int i : kv.second)
-            if (h[i].rt0 <= bs && h[i].rt1 >= be) {
-                const double life = (double)(h[i].rt1 - h[i].rt0);
-                instr += n_instr * (double)(be - bs) / life;
-                cyc_per_tick += cyc[i] / life;
-                ++alive;
-            }
-        if (!alive || instr <= 0) continue;
-        const double win_cyc = (double)(be - bs) * cyc_per_tick / alive;
+        // The SIMD's throughput: every instruction its waves retired, over the span from its first wave's entry to its last wave's exit.
+        // (NOT a per-wave time divided by the occupancy, and not an "overlap window": arbitration is oldest-first, so the waves of a SIMD
+        // do not share it evenly — the oldest runs at its lone-wave rate and finishes first; see the wave-life figures of VM_DEBUG.)
+        unsigned long long s0 = ~0ull, s1 = 0; double cyc_per_tick = 0.0; int alive = 0;
+        for (int i : kv.second) {
+            s0 = std::min(s0, h[i].rt0); s1 = std::max(s1, h[i].rt1);
+            cyc_per_tick += cyc[i] / (double)(h[i].rt1 - h[i].rt0);
+            if (h[i].rt0 <= bs && h[i].rt1 >= be) ++alive;
+        }
+        const double instr = n_instr * (double)kv.second.size();
+        const double win_cyc = (double)(s1 - s0) * cyc_per_tick / (double)kv.second.size();
+        if (!alive) continue;
         resid.push_back((double)alive);
         rate.push_back(win_cyc / instr);
     }
@@ -262,8 +262,8 @@ int main() {
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     printf("# tools/valu_micro.hip (round 5): cycles per wave64 instruction.  /wave: as the median wave sees it (empty loop subtracted).  res: waves\n"
-           "# observed resident together on a SIMD (HW_ID + s_memrealtime record).  /SIMD: cycles of the overlap window per instruction retired in it\n"
-           "# by those waves.  wall: launch time by HIP events x clock / instructions handed to one SIMD; x = /SIMD : wall (1.00 = they agree).\n"
+           "# observed resident together on a SIMD at its busiest moment (HW_ID + s_memrealtime record).  /SIMD: device-side span of the SIMD (first\n"
+           "# entry to last exit of its waves) per instruction its waves retired.  wall: launch time by HIP events x clock / instructions handed to one SIMD; x = /SIMD : wall (1.00 = they agree).\n"
            "device %s, %d CUs, clockRate %d kHz\n", prop.name, cus, prop.clockRate);
     Rec* dbuf;
     CHECK(hipMalloc(&dbuf, (size_t)cus * 32 * sizeof(Rec)));
