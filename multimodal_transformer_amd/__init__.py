@@ -3,7 +3,7 @@
 ``multiTransformer`` mirrors the reference module of the same name; ``functional`` holds the
 autograd bindings of the HIP entry points declared in ``include/mmt_hip.h``.
 """
-from . import _lib, batching, functional, graphs, multiTransformer, optim  # noqa: F401
+from . import _lib, batching, functional, graphs, models, multiTransformer, optim  # noqa: F401
 from .metrics import batched_ccc, eval_ccc  # noqa: F401
 
-__all__ = ["functional", "multiTransformer", "batching", "optim", "graphs", "eval_ccc", "batched_ccc"]
+__all__ = ["functional", "multiTransformer", "models", "batching", "optim", "graphs", "eval_ccc", "batched_ccc"]

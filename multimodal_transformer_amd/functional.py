@@ -336,6 +336,14 @@ class _LinearFn(torch.autograd.Function):
 def linear(x, weight, bias=None, act=0, rowscale=None, in_dropout=0.0, out_dropout=0.0, seed=0):
     """y = rowscale * drop_out(act(drop_in(x) W^T + b)); act: 0 none, 1 ReLU, 2 tanh, 3 sigmoid.  in_dropout / out_dropout: train-mode
     dropout probabilities fused into the kernel (out_dropout behind ReLU only); seed: python int or ``_lib.DeviceSeed``."""
+    K = x.shape[-1]
+    if K % 4:
+        # the row kernels stage their A tile in 16-byte pieces of fp32: an input width that is no multiple of 4 (none occurs in the reference's
+        # models) is brought to the next one with zero columns on x and on W — the product is unchanged, the gradients of the pads are dropped
+        # by cat_cols' backward (an input-dropout mask then indexes the padded width, like every mask indexes padded leading dimensions)
+        pad = 4 - K % 4
+        x = cat_cols([x, torch.zeros(*x.shape[:-1], pad, dtype=x.dtype, device=x.device)])
+        weight = cat_cols([weight, torch.zeros(weight.shape[0], pad, dtype=weight.dtype, device=weight.device)])
     return _LinearFn.apply(x, weight, bias, rowscale, int(act), float(in_dropout), float(out_dropout),
                            seed if isinstance(seed, _lib.DeviceSeed) else int(seed))
 

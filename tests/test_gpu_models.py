@@ -502,6 +502,28 @@ def test_linear_fused_dropout_replay(dev, in_p, out_p):
     assert float((y2 - y.detach()).abs().max()) > 1e-3            # another seed, another mask
 
 
+@pytest.mark.parametrize("K", [5, 43, 301])
+def test_linear_with_an_input_width_that_is_no_multiple_of_four(dev, K):
+    """nn.Linear accepts any in_features (the reference's own widths are all multiples of 4: 300, 88, 44, 256, 512, 812 ...); the row kernels
+    stage 16-byte pieces, so functional.linear pads x and W with zero columns: same product, gradients of the real columns unchanged."""
+    F = mta().functional
+    M, N = 37, 24
+    x = R.gen_normal("oddK:x", (M, K), 3)
+    W = R.gen_normal("oddK:W", (N, K), 3) * 0.2
+    b = R.gen_normal("oddK:b", (N,), 3) * 0.1
+    g = R.gen_normal("oddK:g", (M, N), 3)
+    xs, Ws, bs = (t.to(dev).requires_grad_() for t in (x, W, b))
+    y = F.linear(xs, Ws, bs, act=2)
+    y.backward(g.to(dev))
+    xd, Wd, bd = (t.double().requires_grad_() for t in (x, W, b))
+    ref = torch.tanh(xd @ Wd.t() + bd)
+    ref.backward(g.double())
+    assert _report("odd K=%d y" % K, y.detach().cpu(), ref.detach()) < OUT_RTOL
+    assert _report("odd K=%d dx" % K, xs.grad.cpu(), xd.grad) < GRAD_RTOL
+    assert _report("odd K=%d dW" % K, Ws.grad.cpu(), Wd.grad) < GRAD_RTOL
+    assert _report("odd K=%d db" % K, bs.grad.cpu(), bd.grad) < GRAD_RTOL
+
+
 def _device_kernel_names(step):
     """names of the device kernels one call of `step` launches (torch.profiler); None if the profiler reports no device activity"""
     from torch.profiler import profile, ProfilerActivity
