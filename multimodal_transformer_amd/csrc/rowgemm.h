@@ -19,24 +19,8 @@
 #pragma once
 #include "common.h"
 
-// ---- developer instrumentation (never in the shipped build): per-workgroup cycle stamps at the phase boundaries of a stage.
-#ifdef MMT_PHASE_TIMING
-__device__ unsigned long long* g_phase_buf = nullptr;      // [workgroup][stage slot 0..3][phase 0..7] accumulated cycles
-// Stamps are accumulated in registers of thread 0 and flushed once per stage into the workgroup's PRIVATE slots with plain
-// stores: an atomic per mark costs ~7k cycles, and contended atomics at the end of a stage make the next stage wait ~25k
-// cycles for them — both artefacts were larger than the phases they were meant to measure.
-#define PHASE_DECL unsigned long long t_phase_ = __builtin_readcyclecounter(), acc_phase_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
-    const int slot_phase_ = (EPI == EPI_FRAG) ? 0 : (EPI == EPI_LNBWD ? 1 : (LNPRO ? 2 : 3));
-#define PHASE(n) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); \
-    acc_phase_[n] += now_ - t_phase_; t_phase_ = now_; } } while (0)
-#define PHASE_FLUSH do { if (threadIdx.x == 0 && g_phase_buf) { unsigned long long* q_ = g_phase_buf + ((size_t)blockIdx.x * 4 + slot_phase_) * 8; \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) if (acc_phase_[i_]) q_[i_] += acc_phase_[i_]; } } while (0)
-#else
-#define PHASE_DECL
-#define PHASE(n)
-#define PHASE_FLUSH
-#endif
-
+// (`//@phase` comment lines mark the phase boundaries of a stage: tools/build_phase.sh builds a diagnostic library from a PATCHED COPY of this
+// file in which they are cycle stamps — tools/make_phase.py; this file holds no diagnostic code)
 enum { EPI_PLAIN = 0, EPI_FRAG = 1, EPI_LNBWD = 2 };
 
 // Tile geometry.  These kernels are bound by INSTRUCTION ISSUE, not by MFMA or memory: a wave issues at most one vector
@@ -166,7 +150,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     constexpr int ROWS = MMT_ROWS, TPR = MMT_RTPR, MT = MMT_ROWS / 16;
     const int m0 = blockIdx.x * ROWS;
     const int l15 = lane & 15, lq = lane >> 4;
-    PHASE_DECL
+    //@phase decl
 
     // W fragments (straight from L2, ~1k cycles away) travel through a ring of PFD k-blocks per wave.  The first PFD blocks of the
     // first chunk go in flight NOW: their latency overlaps the A-tile staging.  (Requesting the NEXT stage's first blocks behind a stage's
@@ -175,22 +159,12 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
     constexpr int PFD = rowgemm_pfd<EPI, ASRC, KEEP, WIDE>();
     bf16x8 wf[PFD][2][MMT_WNT];                                   // [slot][k half: +0 / +32][16-column tile of the wave]
     auto w_load = [&](int slot, int nb, int kb) {                 // slot and the guard are compile-time / wave-uniform
-#ifdef MMT_ABL_WCONST   // timing-only ablation (results are WRONG): every W fragment from the same 2 KB, i.e. from the CU's L1 — an upper bound on what
-        // weights held in LDS by a persistent workgroup could save on the L2 -> CU fragment fetches
-        const bf16* wr = p.W + (size_t)l15 * KP + 8 * lq; (void)nb; (void)kb;
-#pragma unroll
-        for (int b = 0; b < MMT_WNT; ++b) {
-            wf[slot][0][b] = *reinterpret_cast<const bf16x8*>(wr);
-            wf[slot][1][b] = *reinterpret_cast<const bf16x8*>(wr + 32);
-        }
-#else
         const bf16* wr = p.W + (size_t)(nb + l15) * KP + 8 * lq + kb;
 #pragma unroll
         for (int b = 0; b < MMT_WNT; ++b) {
             wf[slot][0][b] = *reinterpret_cast<const bf16x8*>(wr + (size_t)16 * b * KP);
             wf[slot][1][b] = *reinterpret_cast<const bf16x8*>(wr + (size_t)16 * b * KP + 32);
         }
-#endif
     };
     auto w_prime = [&](int nb) {
 #pragma unroll
@@ -302,7 +276,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         }
     }
     __syncthreads();
-    PHASE(0);                                                 // A tile staged (LayerNorm prologue included)
+    //@phase 0: A tile staged (LayerNorm prologue included)
 
     if (p.A_out) {    // row-major copy of the bf16 tile (16-byte pieces, whole rows contiguous)
         for (int row = tid >> 3; row < ROWS; row += MMT_RTHREADS / 8)
@@ -312,7 +286,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
         }
     }
 
-    PHASE(1);                                                 // row-major copy of the A tile
+    //@phase 1: row-major copy of the A tile
     // ------------------------------------------------------------------ 2. chunks of 128 columns
     for (int n0 = 0; n0 < NP; n0 += 128) {
         const int nb = n0 + wave * MMT_WCOLS;
@@ -365,9 +339,9 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
                             Fs[(mt * 16 + 4 * lq + r) * ldf + cbase + nt * 16] = acc[mt][nt][r];
             }
         }
-        if (EPI == EPI_LNBWD) { PHASE(2); continue; }
+        if (EPI == EPI_LNBWD) { /*@phase 2*/ continue; }
         __syncthreads();
-        PHASE(2);                                             // k-loop + accumulators parked
+        //@phase 2: k-loop + accumulators parked
 
         // -------------------------------------------------------------- 3. row-wise epilogue (chunk)
         if (EPI == EPI_PLAIN) {
@@ -532,7 +506,7 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             }
         }
         __syncthreads();
-        PHASE(3);                                             // chunk epilogue (PLAIN / FRAG)
+        //@phase 3: chunk epilogue (PLAIN / FRAG)
     }
 
     // ------------------------------------------------------------------ LayerNorm backward epilogue
@@ -738,9 +712,9 @@ __device__ __forceinline__ void rowgemm_stage(const RowGemmParams& p, const RowS
             }
         }
         __syncthreads();
-        PHASE(4);                                             // LayerNorm-backward epilogue + column partials
+        //@phase 4: LayerNorm-backward epilogue + column partials
     }
-    PHASE_FLUSH;
+    //@phase flush
 }
 
 // (kernel definitions that use the chained stages follow the stage template below)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Developer tool: per-phase cycle split of the row-GEMM stages.  Needs tools/bin/libmmt_phase.so:
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DMMT_PHASE_TIMING -o tools/bin/libmmt_phase.so multimodal_transformer_amd/csrc/api.hip"""
+"""Developer tool: per-phase cycle split of the row-GEMM stages.  Needs tools/bin/libmmt_phase.so (tools/build_phase.sh: the `//@phase`
+markers of rowgemm.h turned into cycle stamps in a patched copy of the sources)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["MMT_LIB_PATH"] = os.path.join(ROOT, "tools", "bin", "libmmt_phase.so")
